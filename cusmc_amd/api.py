@@ -1,0 +1,381 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+Same names and argument meaning as the reference:
+
+  R level  (R/RcppExports.R:17-103; bodies src/*.rcpp.cpp)
+      MVN(mu, sigma)  MVNPDF(x, mu, sigma)  MVT(mu, sigma, nu)  MVTPDF(x, mu, sigma, nu)
+      metropolis_hastings(w, N, B)  run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler,
+      distribution, p=0)
+  C++ level (inst/include/statistics.hpp:36-250, inst/include/samplers.hpp:7-18)
+      MultiVariateNormalDistribution(mu, sigma) / MultiVariateTStudentDistribution(mu, sigma, nu)
+      with pdf(y), pdf(y, F), getNorm(), sample(Q, n);  Sampler.metropolis_hastings(...)
+
+This module holds no arithmetic of its own: every number comes out of libcusmc_hip.so.  The
+Rcpp glue in rcpp/src binds the same C ABI for R (it cannot be compiled in this image, which
+has no R), so this is the layer the parity tests drive.
+
+Conventions carried over from R: matrices arrive as numpy arrays indexed [row, col] like R's;
+`Y` is d x T with columns = time (src/run.rcpp.cpp:91); a batched `x` is d x N with columns =
+particles.  Densities (not logs) are returned wherever the reference returns densities.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import MVN as _MVN, MVT as _MVT, OUT_DENSITY, OUT_LOG, CusmcError, check
+
+__all__ = ["Context", "MultiVariateNormalDistribution", "MultiVariateTStudentDistribution",
+           "Sampler", "MVN", "MVNPDF", "MVT", "MVTPDF", "metropolis_hastings", "run",
+           "set_seed", "eigenSolver", "CusmcError"]
+
+SQRT3 = 1.7320508075688772  # the reference CPU transform's std-dev inflation
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU + stream (cusmc_ctx).  The reference has no such object: it implicitly uses device
+    0 and resets it after every call (src/mvn_dist.cu.cpp:788)."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        check(_lib.lib().cusmc_ctx_create(device, C.byref(self._h)))
+
+    def set_stream(self, stream_ptr):
+        check(_lib.lib().cusmc_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+        return self
+
+    def synchronize(self):
+        check(_lib.lib().cusmc_ctx_synchronize(self._h))
+
+    @property
+    def num_cus(self):
+        n = C.c_int()
+        check(_lib.lib().cusmc_ctx_num_cus(self._h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self._h:
+            _lib.lib().cusmc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+_rng = {"seed": None, "calls": 0}
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def set_seed(seed):
+    """Seed the R-level draw / resample functions.  The reference cannot be seeded at all
+    (std::random_device per call: src/samplers.cpp:10-11); unseeded, this module behaves the same
+    way (a fresh seed from the OS), but CUSMC_SEED or set_seed() make runs reproducible."""
+    _rng["seed"] = int(seed) & (2 ** 64 - 1)
+    _rng["calls"] = 0
+
+
+def _next_stream():
+    if _rng["seed"] is None:
+        env = os.environ.get("CUSMC_SEED")
+        set_seed(int(env) if env is not None else int.from_bytes(os.urandom(8), "little"))
+    _rng["calls"] += 1
+    return _rng["seed"], _rng["calls"]
+
+
+def eigenSolver(sigma):
+    """eigenSolver(I_sol, sigma) -- src/linear_algebra.cpp:10-23: Q = V sqrt(Lambda)."""
+    sigma = _f64(sigma)
+    Q = np.empty_like(sigma)
+    check(_lib.lib().cusmc_eigen_sqrt(_ptr(sigma), sigma.shape[0], _ptr(Q)))
+    return Q
+
+
+class _Distribution:
+    """StatisticalDistribution (inst/include/statistics.hpp:36-96) over a cusmc_dist handle."""
+    _kind = _MVN
+
+    def __init__(self, mu, sigma, nu=0.0, ctx=None):
+        self.ctx = ctx or default_context()
+        self.sigma = _f64(sigma)
+        if self.sigma.ndim != 2 or self.sigma.shape[0] != self.sigma.shape[1]:
+            raise ValueError("sigma must be a square matrix")
+        self.d = self.sigma.shape[0]
+        self.mu = _f64(np.zeros(self.d) if mu is None else mu).reshape(-1)
+        if self.mu.shape[0] != self.d:
+            raise ValueError("mu has %d entries, sigma is %d x %d" % (self.mu.shape[0], self.d, self.d))
+        self.nu = float(np.float32(nu))
+        self._h = C.c_void_p()
+        check(_lib.lib().cusmc_dist_create(self.ctx._h, self._kind, _ptr(self.mu), _ptr(self.sigma),
+                                           self.d, C.c_float(self.nu), C.byref(self._h)))
+
+    # -- scalar interface, as the reference's virtuals ---------------------------------------
+    def pdf(self, y, F=None):
+        """pdf(y) / pdf(y, F) -- src/statistics.cc.cpp:171-196 (mvn), :295-324 (mvt).
+        NB pdf(y) IGNORES mu, exactly like the reference's one-argument overload."""
+        y = _f64(y).reshape(1, -1)
+        if F is None:
+            # pdf(y): quadratic form in y itself -> reweight form with x = 0... i.e. y - I*0
+            out = self.reweight(np.zeros((1, self.d)), y.reshape(-1), np.eye(self.d), log=False)
+        else:
+            out = self.pdf_batch(y, F, log=False)
+        return float(out[0])
+
+    def getNorm(self):
+        """getNorm() -- src/statistics.cc.cpp:205-211, :332-340 (returned as the reference does,
+        not as a log)."""
+        return float(np.exp(self.lognorm()))
+
+    def lognorm(self):
+        v = C.c_double()
+        check(_lib.lib().cusmc_dist_lognorm(self._h, C.byref(v)))
+        return v.value
+
+    def logdet(self):
+        v = C.c_double()
+        check(_lib.lib().cusmc_dist_logdet(self._h, C.byref(v)))
+        return v.value
+
+    def mean(self):
+        return self.mu.copy()
+
+    def stdev(self):
+        return self.sigma.copy()  # sic: the reference returns sigma (statistics.cc.cpp:221)
+
+    # -- batched interface (host buffers) -----------------------------------------------------
+    def pdf_batch(self, X, F=None, log=True):
+        """out[i] = (log) p(X[i]; F mu, Sigma): pdf(y, F) over N x d rows."""
+        X = _f64(X)
+        if X.ndim != 2 or X.shape[1] != self.d:
+            raise ValueError("X must be N x %d" % self.d)
+        Fm = None if F is None else _f64(F)
+        out = np.empty(X.shape[0])
+        check(_lib.lib().cusmc_dist_pdf_host(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(Fm),
+                                             OUT_LOG if log else OUT_DENSITY, _ptr(out)))
+        return out
+
+    def reweight(self, X, y, F, log=True):
+        """out[i] = (log) p(y - F X[i]; 0, Sigma): reweight_G (src/mcmc.cpp:185-215)."""
+        X, y = _f64(X), _f64(y).reshape(-1)
+        if X.ndim != 2 or X.shape[1] != self.d or y.shape[0] != self.d:
+            raise ValueError("X must be N x %d and y of length %d" % (self.d, self.d))
+        Fm = None if F is None else _f64(F)
+        out = np.empty(X.shape[0])
+        check(_lib.lib().cusmc_dist_reweight_host(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(y),
+                                                  _ptr(Fm), OUT_LOG if log else OUT_DENSITY,
+                                                  _ptr(out)))
+        return out
+
+    # -- batched interface (device-resident torch tensors) -----------------------------------
+    @staticmethod
+    def _tensor_args(X, out):
+        import torch
+        if not (X.is_cuda and out.is_cuda and X.dtype == torch.float64 and out.dtype == torch.float64):
+            raise ValueError("X and out must be float64 CUDA tensors")
+        if X.dim() != 2 or X.stride(1) != 1 or not out.is_contiguous() or out.numel() != X.shape[0]:
+            raise ValueError("X must be N x d with unit inner stride; out contiguous of length N")
+        return X.data_ptr(), X.shape[0], (X.stride(0) if X.shape[0] > 1 else X.shape[1]), out.data_ptr()
+
+    def pdf_dev(self, X, out, F=None, log=True):
+        xp, n, ldx, op = self._tensor_args(X, out)
+        Fm = None if F is None else _f64(F)
+        check(_lib.lib().cusmc_dist_pdf_dev(self._h, C.c_void_p(xp), n, ldx, _ptr(Fm),
+                                            OUT_LOG if log else OUT_DENSITY, C.c_void_p(op)))
+        return out
+
+    def reweight_dev(self, X, y, F, out, log=True):
+        xp, n, ldx, op = self._tensor_args(X, out)
+        y = _f64(y).reshape(-1)
+        Fm = None if F is None else _f64(F)
+        check(_lib.lib().cusmc_dist_reweight_dev(self._h, C.c_void_p(xp), n, ldx, _ptr(y), _ptr(Fm),
+                                                 OUT_LOG if log else OUT_DENSITY, C.c_void_p(op)))
+        return out
+
+    # -- draws ---------------------------------------------------------------------------------
+    def sample(self, Q, n_iterations=200, count=1, compat=False, seed=None, step=None):
+        """sample(draws, Q, n_iterations) -- src/statistics.cc.cpp:224-259, :355-412.
+        `n_iterations` only exists for signature parity: the reference's 200-term sum of
+        normals is exactly N(0,3) per component, drawn here in one step when compat=True
+        (scale sqrt(3)); the default is the statistically correct N(0,1)."""
+        del n_iterations
+        if seed is None:
+            seed, step = _next_stream()
+        Q = _f64(Q)
+        out = np.empty((count, self.d))
+        check(_lib.lib().cusmc_sample_host(self.ctx._h, self._kind, C.c_float(self.nu), _ptr(self.mu),
+                                           _ptr(Q), self.d, SQRT3 if compat else 1.0, seed,
+                                           int(step or 0), count, _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().cusmc_dist_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiVariateNormalDistribution(_Distribution):
+    """inst/include/statistics.hpp:142-195; src/statistics.cc.cpp:155-272."""
+    _kind = _MVN
+
+    def __init__(self, mu, sigma, ctx=None):
+        super().__init__(mu, sigma, 0.0, ctx)
+
+
+class MultiVariateTStudentDistribution(_Distribution):
+    """inst/include/statistics.hpp:197-250; src/statistics.cc.cpp:276-424."""
+    _kind = _MVT
+
+    def __init__(self, mu, sigma, nu, ctx=None):
+        super().__init__(mu, sigma, nu, ctx)
+
+    def dfree(self):
+        return self.nu
+
+
+class Sampler:
+    """inst/include/samplers.hpp:7-18."""
+
+    @staticmethod
+    def metropolis_hastings(w, N=None, t=1, B=10, seed=0, ctx=None):
+        """Sampler::metropolis_hastings(a_t, w_t, N, t, B) -- src/samplers.cpp:7-36.  Takes the
+        weight vector w_t[t-1] and returns the row a_t[t*N : (t+1)*N] (uint32, 0-based)."""
+        ctx = ctx or default_context()
+        w = _f64(w).reshape(-1)
+        N = w.shape[0] if N is None else int(N)
+        if N > w.shape[0]:
+            raise ValueError("N = %d exceeds the %d weights given" % (N, w.shape[0]))
+        a = np.empty(N, dtype=np.uint32)
+        check(_lib.lib().cusmc_metropolis_host(ctx._h, _ptr(w), N, int(B), int(seed), int(t), _ptr(a)))
+        return a
+
+    @staticmethod
+    def metropolis_hastings_dev(w, a, B=10, t=1, seed=0, first=0, ctx=None):
+        """Device-resident: w float64 CUDA tensor (all N weights), a int32/uint32-sized CUDA
+        tensor receiving the ancestors of chains [first, first + len(a))."""
+        ctx = ctx or default_context()
+        check(_lib.lib().cusmc_metropolis_dev(ctx._h, C.c_void_p(w.data_ptr()), w.numel(), int(B),
+                                              int(seed), int(t), int(first), a.numel(),
+                                              C.c_void_p(a.data_ptr())))
+        return a
+
+
+# ---- R-level exports ----------------------------------------------------------------------------
+
+def _batched_density(dist, x, d):
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        if x.shape[0] != d:
+            raise ValueError("x has %d entries, mu has %d" % (x.shape[0], d))
+        return float(dist.pdf_batch(x.reshape(1, d), None, log=False)[0])
+    if x.ndim == 2 and x.shape[0] == d:  # d x N, columns = particles (R layout)
+        return dist.pdf_batch(np.ascontiguousarray(x.T), None, log=False)
+    raise ValueError("x must be a length-d vector or a d x N matrix")
+
+
+def MVNPDF(x, mu, sigma):
+    """double MVNPDF(x, mu, sigma) -- src/mvn_dist.rcpp.cpp:52-58: F = I; MVN(mu,sigma).pdf(x, F).
+    Returns the DENSITY.  Batched extension: a d x N matrix x returns N densities."""
+    dist = MultiVariateNormalDistribution(mu, sigma)
+    try:
+        return _batched_density(dist, x, dist.d)
+    finally:
+        dist.close()
+
+
+def MVTPDF(x, mu, sigma, nu):
+    """double MVTPDF(x, mu, sigma, nu) -- src/mvt_dist.rcpp.cpp:60-66."""
+    dist = MultiVariateTStudentDistribution(mu, sigma, nu)
+    try:
+        return _batched_density(dist, x, dist.d)
+    finally:
+        dist.close()
+
+
+def MVN(mu, sigma, compat=False):
+    """VectorXd MVN(mu, sigma) -- src/mvn_dist.rcpp.cpp:31-37.  The reference passes `sigma`
+    ITSELF as the square-root factor Q (:35) and inflates the variance 3x (F6); compat=True
+    reproduces that distribution, the default draws from N(mu, sigma)."""
+    dist = MultiVariateNormalDistribution(mu, sigma)
+    try:
+        Q = dist.sigma if compat else eigenSolver(dist.sigma)
+        return dist.sample(Q, 200, compat=compat)[0]
+    finally:
+        dist.close()
+
+
+def MVT(mu, sigma, nu, compat=False):
+    """VectorXd MVT(mu, sigma, nu) -- src/mvt_dist.rcpp.cpp:28-49 (Q = eigen square root)."""
+    dist = MultiVariateTStudentDistribution(mu, sigma, nu)
+    try:
+        return dist.sample(eigenSolver(dist.sigma), 200, compat=compat)[0]
+    finally:
+        dist.close()
+
+
+def metropolis_hastings(w, N, B):
+    """VectorXd metropolis_hastings(w, N, B) -- src/samplers.rcpp.cpp:35-55: t = 1, returns the
+    N ancestors as DOUBLES, 0-based, like the reference."""
+    seed, call = _next_stream()
+    # the call counter takes the place of t so that successive R-level calls are independent
+    return Sampler.metropolis_hastings(w, N, t=call, B=B, seed=seed).astype(np.float64)
+
+
+def run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p=0, B=10,
+        compat=False, seed=None, write_csv=False, return_ancestors=False):
+    """List run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p)
+    -- src/run.rcpp.cpp:58-126.  Returns {"weights": T x N, "posterior_x": T x N x d}.
+    df reaches the filter as df (the reference passes it in the wrong slot: SURVEY.md F8).
+    B = 10 is the reference's hard-coded value (src/mcmc.cpp:291)."""
+    N, d, T = int(N), int(d), int(timeSteps)
+    if not 0 <= int(p) < N:
+        raise ValueError("p = %d must satisfy 0 <= p < N" % p)  # assert(p < N): run.rcpp.cpp:64
+    Y = _f64(Y)
+    if Y.shape != (d, T):
+        raise ValueError("Y must be d x timeSteps (columns = time), got %s" % (Y.shape,))
+    Yt = np.ascontiguousarray(Y.T)
+    m0, C0, F, G, V, W = (_f64(a) for a in (m0, C0, F, G, V, W))
+    if seed is None:
+        seed, _ = _next_stream()
+    ctx = default_context()
+    X = np.empty((T, N, d))
+    w = np.empty((T, N))
+    a = np.empty((T, N), dtype=np.uint32)
+    check(_lib.lib().cusmc_pf_run_host(ctx._h, _ptr(Yt), N, d, T, _ptr(m0), _ptr(C0), _ptr(F), _ptr(G),
+                                       _ptr(V), _ptr(W), C.c_float(df), str(resampler).encode(),
+                                       str(distribution).encode(), int(B),
+                                       SQRT3 if compat else 1.0, int(seed), _ptr(X), _ptr(w), _ptr(a)))
+    if write_csv:
+        from .io import writeOutput
+        writeOutput(Yt, w, X, N, d, T, int(p))
+    out = {"weights": w, "posterior_x": X}
+    if return_ancestors:
+        out["ancestors"] = a
+    return out

@@ -1,0 +1,625 @@
+// libcusmc_hip.so -- implementation of the C ABI declared in include/cusmc_hip.h.
+// Host side only: contexts, the distribution objects (factor once, upload once), argument
+// checking, dispatch to the gfx950 kernels under kernels/.  No CPU compute fallback exists: a
+// call without a usable device fails with CUSMC_ENODEVICE / CUSMC_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cusmc_hip.h"
+#include "hostla.h"
+#include "launch.h"
+
+#define CUSMC_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+// The reference's CUDA_CALL prints and Rcpp::stop()s (inst/include/support.cuh:9-14,26);
+// here a failing HIP call becomes a status code + message and the glue raises the R error.
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(CUSMC_EHIP, "%s in %s at line %d", hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes)
+  {
+    if (bytes <= cap) return CUSMC_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(&p, bytes));
+    cap = bytes;
+    return CUSMC_OK;
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct cusmc_ctx {
+  int device = 0;
+  int num_cus = 0;
+  hipStream_t stream = nullptr;
+  DevBuf scratch[6];  // host-pointer entry points: X, out, w, a, small matrices
+};
+
+struct cusmc_dist {
+  cusmc_ctx *ctx = nullptr;
+  int kind = CUSMC_MVN;
+  int d = 0;
+  float nu = 0.f;
+  double logdet = 0.0, lognorm = 0.0;
+  std::vector<double> mu, W;  // W = L^-1, row-major lower triangular
+  // device images of the current (M, shift, bias) plan
+  DevBuf frags, Mdev, shift, bias;
+  // what is currently uploaded, to skip redundant uploads in time loops
+  int plan = 0;  // 0 none, 1 centred, 2 affine
+  bool plan_tri = true;
+  std::vector<double> plan_F, plan_shift, plan_bias;
+  bool frags_valid = false, M_valid = false;
+  std::vector<double> hostM;
+};
+
+namespace {
+
+using cusmc::Epilogue;
+
+int activate(cusmc_ctx *ctx)
+{
+  if (!ctx) return fail(CUSMC_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return CUSMC_OK;
+}
+
+Epilogue make_epilogue(const cusmc_dist *dist, int flags)
+{
+  Epilogue ep;
+  ep.lognorm = dist->lognorm;
+  const float nu_plus_d = dist->nu + (float)dist->d;  // float arithmetic, as the reference
+  ep.half_nu_plus_d = 0.5 * (double)nu_plus_d;
+  ep.inv_nu = dist->kind == CUSMC_MVT ? 1.0 / (double)dist->nu : 0.0;
+  ep.kind = dist->kind;
+  ep.out_density = (flags & CUSMC_OUT_DENSITY) ? 1 : 0;
+  return ep;
+}
+
+// Install the plan z = bias + M (x - shift) on the device.  Re-uploads only what changed.
+int install_plan(cusmc_dist *dist, int plan, bool tri, const std::vector<double> &M,
+                 const double *F_key, const std::vector<double> &shift,
+                 const std::vector<double> &bias)
+{
+  cusmc_ctx *ctx = dist->ctx;
+  const int d = dist->d;
+  const size_t dd = (size_t)d * d;
+  bool same_M = dist->plan == plan && dist->plan_tri == tri;
+  if (same_M) {
+    if (F_key)
+      same_M = dist->plan_F.size() == dd && !memcmp(dist->plan_F.data(), F_key, dd * 8);
+    else
+      same_M = dist->plan_F.empty();
+  }
+  if (!same_M) {
+    dist->hostM = M;
+    dist->frags_valid = false;
+    dist->M_valid = false;
+    dist->plan = plan;
+    dist->plan_tri = tri;
+    if (F_key) dist->plan_F.assign(F_key, F_key + dd); else dist->plan_F.clear();
+  }
+  // shift / bias: padded to a multiple of 16 entries for the MFMA kernel's LDS image
+  const size_t padded = (size_t)((d + 15) / 16) * 16;
+  if (dist->plan_shift != shift || dist->shift.p == nullptr) {
+    std::vector<double> tmp(padded, 0.0);
+    std::copy(shift.begin(), shift.end(), tmp.begin());
+    if (int rc = dist->shift.reserve(padded * 8)) return rc;
+    HIP_TRY(hipMemcpyAsync(dist->shift.p, tmp.data(), padded * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // tmp is a stack-lifetime staging buffer
+    dist->plan_shift = shift;
+  }
+  if (dist->plan_bias != bias || dist->bias.p == nullptr) {
+    std::vector<double> tmp(padded, 0.0);
+    std::copy(bias.begin(), bias.end(), tmp.begin());
+    if (int rc = dist->bias.reserve(padded * 8)) return rc;
+    HIP_TRY(hipMemcpyAsync(dist->bias.p, tmp.data(), padded * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    dist->plan_bias = bias;
+  }
+  return CUSMC_OK;
+}
+
+int ensure_frags(cusmc_dist *dist)
+{
+  if (dist->frags_valid) return CUSMC_OK;
+  const int d = dist->d, nb = d / 16;
+  const size_t n = (size_t)cusmc::mfma_num_frags(nb, dist->plan_tri) * 64;
+  std::vector<double> frags(n);
+  cusmc::mfma_pack_frags(dist->hostM.data(), d, dist->plan_tri, frags.data());
+  if (int rc = dist->frags.reserve(n * 8)) return rc;
+  HIP_TRY(hipMemcpyAsync(dist->frags.p, frags.data(), n * 8, hipMemcpyHostToDevice, dist->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(dist->ctx->stream));
+  dist->frags_valid = true;
+  return CUSMC_OK;
+}
+
+int ensure_M(cusmc_dist *dist)
+{
+  if (dist->M_valid) return CUSMC_OK;
+  const size_t n = (size_t)dist->d * dist->d;
+  if (int rc = dist->Mdev.reserve(n * 8)) return rc;
+  HIP_TRY(hipMemcpyAsync(dist->Mdev.p, dist->hostM.data(), n * 8, hipMemcpyHostToDevice, dist->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(dist->ctx->stream));
+  dist->M_valid = true;
+  return CUSMC_OK;
+}
+
+int run_logpdf(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx, int flags,
+               double *out_dev)
+{
+  cusmc_ctx *ctx = dist->ctx;
+  const Epilogue ep = make_epilogue(dist, flags);
+  const int d = dist->d;
+  if (cusmc::mfma_supported(d, X_dev, ldx)) {
+    if (int rc = ensure_frags(dist)) return rc;
+    HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan_tri, (const double *)dist->frags.p,
+                                      (const double *)dist->shift.p, (const double *)dist->bias.p,
+                                      ep, out_dev, ctx->num_cus, ctx->stream));
+    return CUSMC_OK;
+  }
+  if (!cusmc::generic_supported(d))
+    return fail(CUSMC_ERANGE, "d = %d is beyond the generic log-pdf kernel (and not a multiple of 16)", d);
+  if (int rc = ensure_M(dist)) return rc;
+  HIP_TRY(cusmc::launch_logpdf_generic(X_dev, N, ldx, d, dist->plan_tri, (const double *)dist->Mdev.p,
+                                       (const double *)dist->shift.p, (const double *)dist->bias.p,
+                                       ep, out_dev, ctx->num_cus, ctx->stream));
+  return CUSMC_OK;
+}
+
+int check_batch(const cusmc_dist *dist, const void *X, int64_t N, int64_t ldx, const void *out)
+{
+  if (!dist) return fail(CUSMC_EINVAL, "null distribution");
+  if (N < 0) return fail(CUSMC_EINVAL, "N = %lld is negative", (long long)N);
+  if (N > 0 && (!X || !out)) return fail(CUSMC_EINVAL, "null batch or output pointer");
+  if (ldx < dist->d) return fail(CUSMC_EINVAL, "ldx = %lld < d = %d", (long long)ldx, dist->d);
+  return CUSMC_OK;
+}
+
+// centred form:  r = x - F mu   (pdf(y, F); src/statistics.cc.cpp:192, :305)
+int plan_centred(cusmc_dist *dist, const double *F)
+{
+  const int d = dist->d;
+  std::vector<double> shift(dist->mu);
+  if (F && !cusmc::la::is_identity(F, d)) cusmc::la::matvec(F, dist->mu.data(), d, shift);
+  const std::vector<double> bias(d, 0.0);
+  return install_plan(dist, 1, true, dist->W, nullptr, shift, bias);
+}
+
+// affine form:  r = y - F x   (reweight_G; src/mcmc.cpp:208).  With F = I this is the centred
+// form with shift = y (q is even in r), which keeps the factor triangular.
+int plan_affine(cusmc_dist *dist, const double *y, const double *F)
+{
+  const int d = dist->d;
+  if (!y) return fail(CUSMC_EINVAL, "null y");
+  if (!F || cusmc::la::is_identity(F, d)) {
+    const std::vector<double> shift(y, y + d), bias(d, 0.0);
+    return install_plan(dist, 1, true, dist->W, nullptr, shift, bias);
+  }
+  // z = W y - (W F) x
+  std::vector<double> M, bias;
+  const bool cached = dist->plan == 2 && dist->plan_F.size() == (size_t)d * d &&
+                      !memcmp(dist->plan_F.data(), F, (size_t)d * d * 8);
+  if (!cached) {
+    cusmc::la::matmul(dist->W.data(), F, d, M);
+    for (double &v : M) v = -v;
+  }
+  cusmc::la::matvec(dist->W.data(), y, d, bias);
+  const std::vector<double> shift(d, 0.0);
+  return install_plan(dist, 2, false, cached ? dist->hostM : M, F, shift, bias);
+}
+
+}  // namespace
+
+// ---- library / context ----------------------------------------------------------------------
+
+CUSMC_EXPORT const char *cusmc_version(void) { return "cusmc-hip 0.1 (gfx950)"; }
+CUSMC_EXPORT const char *cusmc_last_error(void) { return g_last_error.c_str(); }
+
+CUSMC_EXPORT int cusmc_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+CUSMC_EXPORT int cusmc_ctx_create(int device, cusmc_ctx **out)
+{
+  if (!out) return fail(CUSMC_EINVAL, "null output pointer");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(CUSMC_ENODEVICE, "no HIP device visible: libcusmc_hip has no CPU fallback");
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  if (device >= n) return fail(CUSMC_EINVAL, "device %d out of range (%d visible)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(CUSMC_ENODEVICE, "device %d is %s; this library carries gfx950 code only", device,
+                prop.gcnArchName);
+  cusmc_ctx *ctx = new (std::nothrow) cusmc_ctx;
+  if (!ctx) return fail(CUSMC_EINVAL, "out of host memory");
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount;
+  *out = ctx;
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
+{
+  if (!ctx) return CUSMC_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &b : ctx->scratch) b.release();
+  delete ctx;
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_ctx_set_stream(cusmc_ctx *ctx, void *hip_stream)
+{
+  if (!ctx) return fail(CUSMC_EINVAL, "null context");
+  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_ctx_synchronize(cusmc_ctx *ctx)
+{
+  if (int rc = activate(ctx)) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_ctx_num_cus(cusmc_ctx *ctx, int *out)
+{
+  if (!ctx || !out) return fail(CUSMC_EINVAL, "null argument");
+  *out = ctx->num_cus;
+  return CUSMC_OK;
+}
+
+// ---- distributions --------------------------------------------------------------------------
+
+CUSMC_EXPORT int cusmc_dist_create(cusmc_ctx *ctx, int kind, const double *mu, const double *sigma,
+                                   int d, float nu, cusmc_dist **out)
+{
+  if (!out) return fail(CUSMC_EINVAL, "null output pointer");
+  *out = nullptr;
+  if (int rc = activate(ctx)) return rc;
+  if (kind != CUSMC_MVN && kind != CUSMC_MVT) return fail(CUSMC_EINVAL, "unknown distribution kind %d", kind);
+  if (!sigma) return fail(CUSMC_EINVAL, "null sigma");
+  if (d < 1) return fail(CUSMC_EINVAL, "d = %d must be positive", d);
+  if (d > CUSMC_MAX_DIM) return fail(CUSMC_ERANGE, "d = %d exceeds CUSMC_MAX_DIM = %d", d, CUSMC_MAX_DIM);
+  if (kind == CUSMC_MVT && !(nu > 0.f)) return fail(CUSMC_EINVAL, "nu = %g must be positive", (double)nu);
+
+  std::vector<double> L;
+  const int rc = cusmc::la::cholesky(sigma, d, L);
+  if (rc == -1) return fail(CUSMC_ENOTSPD, "sigma is not symmetric");
+  if (rc) return fail(CUSMC_ENOTSPD, "sigma is not positive definite (pivot %d)", rc - 1);
+
+  cusmc_dist *dist = new (std::nothrow) cusmc_dist;
+  if (!dist) return fail(CUSMC_EINVAL, "out of host memory");
+  dist->ctx = ctx;
+  dist->kind = kind;
+  dist->d = d;
+  dist->nu = kind == CUSMC_MVT ? nu : 0.f;
+  if (mu) dist->mu.assign(mu, mu + d); else dist->mu.assign(d, 0.0);
+  cusmc::la::lower_inverse(L, d, dist->W);
+  double logdet = 0.0;
+  for (int i = 0; i < d; ++i) logdet += 2.0 * std::log(L[(size_t)i * d + i]);
+  dist->logdet = logdet;
+  const double pi = 3.14159265358979323846;
+  if (kind == CUSMC_MVN) {
+    // log of 1 / ((sqrt 2pi)^n det^1/2)                       src/statistics.cc.cpp:205-211
+    dist->lognorm = -0.5 * ((double)d * std::log(2.0 * pi) + logdet);
+  } else {
+    // log of (pi nu)^(-n/2) det^(-1/2) Gamma((nu+n)/2) / Gamma(nu/2)   :332-340; lgamma, so no
+    // tgamma overflow at d >~ 340; nu + n in float as the reference computes it
+    const float nu_plus_d = nu + (float)d;
+    dist->lognorm = std::lgamma(0.5 * (double)nu_plus_d) - std::lgamma(0.5 * (double)nu) -
+                    0.5 * (double)d * std::log(pi * (double)nu) - 0.5 * logdet;
+  }
+  *out = dist;
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_dist_destroy(cusmc_dist *dist)
+{
+  if (!dist) return CUSMC_OK;
+  (void)hipSetDevice(dist->ctx->device);
+  (void)hipStreamSynchronize(dist->ctx->stream);
+  dist->frags.release();
+  dist->Mdev.release();
+  dist->shift.release();
+  dist->bias.release();
+  delete dist;
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_dist_lognorm(const cusmc_dist *dist, double *out)
+{
+  if (!dist || !out) return fail(CUSMC_EINVAL, "null argument");
+  *out = dist->lognorm;
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_dist_logdet(const cusmc_dist *dist, double *out)
+{
+  if (!dist || !out) return fail(CUSMC_EINVAL, "null argument");
+  *out = dist->logdet;
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_dist_pdf_dev(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx,
+                                    const double *F, int flags, double *out_dev)
+{
+  if (int rc = check_batch(dist, X_dev, N, ldx, out_dev)) return rc;
+  if (int rc = activate(dist->ctx)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (int rc = plan_centred(dist, F)) return rc;
+  return run_logpdf(dist, X_dev, N, ldx, flags, out_dev);
+}
+
+CUSMC_EXPORT int cusmc_dist_reweight_dev(cusmc_dist *dist, const double *X_dev, int64_t N,
+                                         int64_t ldx, const double *y, const double *F, int flags,
+                                         double *out_dev)
+{
+  if (int rc = check_batch(dist, X_dev, N, ldx, out_dev)) return rc;
+  if (int rc = activate(dist->ctx)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (int rc = plan_affine(dist, y, F)) return rc;
+  return run_logpdf(dist, X_dev, N, ldx, flags, out_dev);
+}
+
+namespace {
+
+// Shared body of the two host-pointer density entry points.
+int host_density(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx, const double *y,
+                 const double *F, int flags, double *out, bool affine)
+{
+  if (int rc = check_batch(dist, X, N, ldx, out)) return rc;
+  cusmc_ctx *ctx = dist->ctx;
+  if (int rc = activate(ctx)) return rc;
+  if (N == 0) return CUSMC_OK;
+  const size_t xbytes = ((size_t)(N - 1) * ldx + dist->d) * 8;
+  if (int rc = ctx->scratch[0].reserve(xbytes)) return rc;
+  if (int rc = ctx->scratch[1].reserve((size_t)N * 8)) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->scratch[0].p, X, xbytes, hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = affine ? plan_affine(dist, y, F) : plan_centred(dist, F)) return rc;
+  if (int rc = run_logpdf(dist, (const double *)ctx->scratch[0].p, N, ldx, flags, (double *)ctx->scratch[1].p))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(out, ctx->scratch[1].p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSMC_OK;
+}
+
+}  // namespace
+
+CUSMC_EXPORT int cusmc_dist_pdf_host(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx,
+                                     const double *F, int flags, double *out)
+{
+  return host_density(dist, X, N, ldx, nullptr, F, flags, out, false);
+}
+
+CUSMC_EXPORT int cusmc_dist_reweight_host(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx,
+                                          const double *y, const double *F, int flags, double *out)
+{
+  return host_density(dist, X, N, ldx, y, F, flags, out, true);
+}
+
+// ---- resampler ------------------------------------------------------------------------------
+
+CUSMC_EXPORT int cusmc_metropolis_dev(cusmc_ctx *ctx, const double *w_dev, uint32_t N, uint32_t B,
+                                      uint64_t seed, uint32_t step, uint32_t first, uint32_t count,
+                                      uint32_t *a_dev)
+{
+  if (int rc = activate(ctx)) return rc;
+  if ((uint64_t)first + count > N) return fail(CUSMC_EINVAL, "shard [%u, %u) exceeds N = %u", first, first + count, N);
+  if (count == 0) return CUSMC_OK;
+  if (!w_dev || !a_dev) return fail(CUSMC_EINVAL, "null weight or ancestor pointer");
+  HIP_TRY(cusmc::launch_metropolis(w_dev, N, B, seed, step, first, count, a_dev, ctx->num_cus, ctx->stream));
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_metropolis_host(cusmc_ctx *ctx, const double *w, uint32_t N, uint32_t B,
+                                       uint64_t seed, uint32_t step, uint32_t *a)
+{
+  if (int rc = activate(ctx)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (!w || !a) return fail(CUSMC_EINVAL, "null weight or ancestor pointer");
+  if (int rc = ctx->scratch[2].reserve((size_t)N * 8)) return rc;
+  if (int rc = ctx->scratch[3].reserve((size_t)N * 4)) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->scratch[2].p, w, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(cusmc::launch_metropolis((const double *)ctx->scratch[2].p, N, B, seed, step, 0, N,
+                                   (uint32_t *)ctx->scratch[3].p, ctx->num_cus, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(a, ctx->scratch[3].p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSMC_OK;
+}
+
+// ---- proposal draws -------------------------------------------------------------------------
+
+namespace {
+
+int upload_small(cusmc_ctx *ctx, DevBuf &buf, size_t offset_doubles, const double *src, size_t n)
+{
+  HIP_TRY(hipMemcpyAsync((double *)buf.p + offset_doubles, src, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  return CUSMC_OK;
+}
+
+int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const uint32_t *a_dev,
+          const double *G, const double *Q, const double *m0, int d, double scale, uint64_t seed,
+          uint32_t step, uint32_t domain, uint32_t first, uint32_t count, double *X_out_dev)
+{
+  if (int rc = activate(ctx)) return rc;
+  if (kind != CUSMC_MVN && kind != CUSMC_MVT) return fail(CUSMC_EINVAL, "unknown distribution kind %d", kind);
+  if (kind == CUSMC_MVT && !(nu > 0.f)) return fail(CUSMC_EINVAL, "nu = %g must be positive", (double)nu);
+  if (d < 1 || !Q) return fail(CUSMC_EINVAL, "bad d or null Q");
+  if (d > 159) return fail(CUSMC_ERANGE, "proposal kernel supports d <= 159 (got %d)", d);
+  if (count == 0) return CUSMC_OK;
+  if (!X_out_dev) return fail(CUSMC_EINVAL, "null output pointer");
+  const size_t dd = (size_t)d * d;
+  // device image: [Q | G | m0]
+  if (int rc = ctx->scratch[4].reserve((2 * dd + d) * 8)) return rc;
+  if (int rc = upload_small(ctx, ctx->scratch[4], 0, Q, dd)) return rc;
+  if (G) { if (int rc = upload_small(ctx, ctx->scratch[4], dd, G, dd)) return rc; }
+  if (m0) { if (int rc = upload_small(ctx, ctx->scratch[4], 2 * dd, m0, d)) return rc; }
+  const double *base = (const double *)ctx->scratch[4].p;
+  HIP_TRY(cusmc::launch_propagate(kind, nu, X_prev_dev, a_dev, G ? base + dd : nullptr, base,
+                                  m0 ? base + 2 * dd : nullptr, d, scale, seed, step, domain, first,
+                                  count, X_out_dev, ctx->num_cus, ctx->stream));
+  return CUSMC_OK;
+}
+
+}  // namespace
+
+CUSMC_EXPORT int cusmc_propagate_dev(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev,
+                                     const uint32_t *a_dev, uint32_t N, int d, const double *G,
+                                     const double *Q, double scale, uint64_t seed, uint32_t step,
+                                     uint32_t first, uint32_t count, double *X_out_dev)
+{
+  if (!ctx) return fail(CUSMC_EINVAL, "null context");
+  if (!G || !X_prev_dev) return fail(CUSMC_EINVAL, "null G or X_prev");
+  if ((uint64_t)first + count > N) return fail(CUSMC_EINVAL, "shard [%u, %u) exceeds N = %u", first, first + count, N);
+  return draws(ctx, kind, nu, X_prev_dev, a_dev, G, Q, nullptr, d, scale, seed, step, 2u, first, count, X_out_dev);
+}
+
+CUSMC_EXPORT int cusmc_initialize_dev(cusmc_ctx *ctx, int kind, float nu, const double *m0,
+                                      const double *Q, int d, double scale, uint64_t seed,
+                                      uint32_t first, uint32_t count, double *X_out_dev)
+{
+  if (!ctx) return fail(CUSMC_EINVAL, "null context");
+  if (!m0) return fail(CUSMC_EINVAL, "null m0");
+  return draws(ctx, kind, nu, nullptr, nullptr, nullptr, Q, m0, d, scale, seed, 0u, 4u, first, count, X_out_dev);
+}
+
+CUSMC_EXPORT int cusmc_sample_host(cusmc_ctx *ctx, int kind, float nu, const double *mu,
+                                   const double *Q, int d, double scale, uint64_t seed,
+                                   uint32_t step, uint32_t count, double *X_out)
+{
+  if (!ctx) return fail(CUSMC_EINVAL, "null context");
+  if (!mu || !X_out) return fail(CUSMC_EINVAL, "null mu or output pointer");
+  if (d < 1) return fail(CUSMC_EINVAL, "d = %d must be positive", d);
+  if (count == 0) return CUSMC_OK;
+  if (int rc = activate(ctx)) return rc;
+  if (int rc = ctx->scratch[5].reserve((size_t)count * d * 8)) return rc;
+  if (int rc = draws(ctx, kind, nu, nullptr, nullptr, nullptr, Q, mu, d, scale, seed, step, 4u, 0, count,
+                     (double *)ctx->scratch[5].p))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(X_out, ctx->scratch[5].p, (size_t)count * d * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_eigen_sqrt(const double *sigma, int d, double *Q)
+{
+  if (!sigma || !Q || d < 1) return fail(CUSMC_EINVAL, "bad argument");
+  cusmc::la::eigen_sqrt(sigma, d, Q);
+  return CUSMC_OK;
+}
+
+// ---- the filter -----------------------------------------------------------------------------
+
+CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T,
+                                   const double *m0, const double *C0, const double *F,
+                                   const double *G, const double *V, const double *W, float df,
+                                   const char *resampler, const char *distribution, uint32_t B,
+                                   double scale, uint64_t seed, double *X_out, double *w_out,
+                                   uint32_t *a_out)
+{
+  if (int rc = activate(ctx)) return rc;
+  // validate the option strings BEFORE any work: the reference default-constructs an empty
+  // std::function for an unknown key and throws bad_function_call mid-run (mcmc.cpp:269-272)
+  if (!resampler || strcmp(resampler, "metropolis") != 0)
+    return fail(CUSMC_EINVAL, "unknown resampler '%s' (known: metropolis)", resampler ? resampler : "(null)");
+  int kind;
+  if (distribution && !strcmp(distribution, "mvn")) kind = CUSMC_MVN;
+  else if (distribution && !strcmp(distribution, "mvt")) kind = CUSMC_MVT;
+  else return fail(CUSMC_EINVAL, "unknown distribution '%s' (known: mvn, mvt)", distribution ? distribution : "(null)");
+  if (!Y || !m0 || !C0 || !F || !G || !V || !W) return fail(CUSMC_EINVAL, "null model argument");
+  if (N == 0 || T == 0 || d < 1) return fail(CUSMC_EINVAL, "N, T and d must be positive");
+
+  std::vector<double> Q0((size_t)d * d), Qw((size_t)d * d);
+  cusmc::la::eigen_sqrt(C0, d, Q0.data());
+  cusmc::la::eigen_sqrt(W, d, Qw.data());
+
+  cusmc_dist *obs = nullptr;  // pdf_{0,V}: reweight_G sets mu = 0, sigma = V (mcmc.cpp:188-189)
+  if (int rc = cusmc_dist_create(ctx, kind, nullptr, V, d, df, &obs)) return rc;
+
+  const size_t slice = (size_t)N * d;
+  DevBuf dX, dw, da;
+  int rc = dX.reserve(slice * T * 8);
+  if (!rc) rc = dw.reserve((size_t)N * T * 8);
+  if (!rc) rc = da.reserve((size_t)N * T * 4);
+  auto cleanup = [&](int code) {
+    (void)hipStreamSynchronize(ctx->stream);
+    dX.release(); dw.release(); da.release();
+    cusmc_dist_destroy(obs);
+    return code;
+  };
+  if (rc) return cleanup(rc);
+  double *X = (double *)dX.p, *w = (double *)dw.p;
+  uint32_t *a = (uint32_t *)da.p;
+
+  // initialize(): x_0 ~ dist(m0).sample(Q0); w_0 = 1/N        src/mcmc.cpp:76-85
+  rc = cusmc_initialize_dev(ctx, kind, df, m0, Q0.data(), d, scale, seed, 0, N, X);
+  if (rc) return cleanup(rc);
+  {
+    std::vector<double> w0(N, 1.0 / (double)N);
+    if (hipMemcpyAsync(w, w0.data(), (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(a, 0, (size_t)N * 4, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+      return cleanup(fail(CUSMC_EHIP, "initial weight upload failed"));
+  }
+  // MCMC(): for t = 1..T-1: resample -> propagate -> reweight   src/mcmc.cpp:292-308
+  for (uint32_t t = 1; t < T; ++t) {
+    rc = cusmc_metropolis_dev(ctx, w + (size_t)(t - 1) * N, N, B, seed, t, 0, N, a + (size_t)t * N);
+    if (!rc) rc = cusmc_propagate_dev(ctx, kind, df, X + (size_t)(t - 1) * slice, a + (size_t)t * N, N, d, G,
+                                      Qw.data(), scale, seed, t, 0, N, X + (size_t)t * slice);
+    if (!rc) rc = cusmc_dist_reweight_dev(obs, X + (size_t)t * slice, N, d, Y + (size_t)t * d, F,
+                                          CUSMC_OUT_DENSITY, w + (size_t)t * N);
+    if (rc) return cleanup(rc);
+  }
+  hipError_t e = hipSuccess;
+  if (X_out) e = hipMemcpyAsync(X_out, X, slice * T * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && w_out) e = hipMemcpyAsync(w_out, w, (size_t)N * T * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && a_out) e = hipMemcpyAsync(a_out, a, (size_t)N * T * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return cleanup(fail(CUSMC_EHIP, "%s copying filter outputs", hipGetErrorString(e)));
+  return cleanup(CUSMC_OK);
+}

@@ -1,0 +1,127 @@
+// Batched multivariate Normal / Student-t log-density, any d <= 319, fp64 -- the shape-agnostic
+// path (d not a multiple of 16, unaligned or odd-stride batches, tiny d).  Same contract as
+// kernels/logpdf_mfma.hip:   z = bias + M (x - shift),  q = z.z,  out = epilogue(q);
+// same reference functions replaced (src/statistics.cc.cpp:171-196, :295-324;
+// src/mvn_dist.cu.cpp:455-668; src/mvt_dist.cu.cpp:356-571).
+//
+// Mapping: lane = particle.  A workgroup stages a tile of T particles through LDS with
+// fully coalesced 8-byte loads (consecutive lanes read consecutive doubles of the flat
+// batch), subtracting `shift` on the way in; each lane then walks its own row.  Rows are padded
+// to an odd number of doubles, so a wave's ds_read_b64 of column k touches 32 distinct banks
+// per half-wave.  M is read with wave-uniform addresses, i.e. scalar loads through the constant
+// cache: the factor costs no VALU or LDS bandwidth here.  For the triangular (centred) form the
+// inner loop stops at the diagonal.
+//
+// Small d is HBM-bound (8d+8 bytes against ~d^2/2 FMAs per particle); this kernel is the
+// fallback for large odd d, not the tuned path.
+#include <hip/hip_runtime.h>
+
+#include "../launch.h"
+#include "../../../include/cusmc_hip.h"
+
+namespace cusmc {
+
+static __device__ __forceinline__ double finish_generic(double q, const Epilogue &ep)
+{
+  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p(q * ep.inv_nu)
+                                     : ep.lognorm - 0.5 * q;
+  return ep.out_density ? exp(lp) : lp;
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void logpdf_generic_kernel(
+    const double *__restrict__ X, long N, long ldx, int d, int tri, const double *__restrict__ M,
+    const double *__restrict__ shift, const double *__restrict__ bias, Epilogue ep,
+    double *__restrict__ out, long num_tiles)
+{
+  extern __shared__ double sR[];  // T rows x stride
+  const int stride = d | 1;
+  const bool flat = (ldx == d);
+
+  for (long tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const long base = tile * T;
+    const long rows = (N - base) < T ? (N - base) : T;
+    const long elems = rows * d;
+    __syncthreads();  // the previous tile's readers are done with sR
+    if (flat) {
+      const double *src = X + base * ldx;
+      int row = (int)(threadIdx.x / d), col = (int)(threadIdx.x % d);
+      const int drow = T / d, dcol = T % d;
+      for (long e = threadIdx.x; e < elems; e += T) {
+        sR[row * stride + col] = src[e] - shift[col];
+        row += drow;
+        col += dcol;
+        if (col >= d) { col -= d; ++row; }
+      }
+    } else {
+      int row = (int)(threadIdx.x / d), col = (int)(threadIdx.x % d);
+      const int drow = T / d, dcol = T % d;
+      for (long e = threadIdx.x; e < elems; e += T) {
+        sR[row * stride + col] = X[(base + row) * ldx + col] - shift[col];
+        row += drow;
+        col += dcol;
+        if (col >= d) { col -= d; ++row; }
+      }
+    }
+    __syncthreads();
+    if ((long)threadIdx.x < rows) {
+      const double *r = sR + threadIdx.x * stride;
+      double q = 0.0;
+      for (int j = 0; j < d; ++j) {
+        const double *Mj = M + (long)j * d;
+        const int kend = tri ? j + 1 : d;
+        double z0 = bias[j], z1 = 0.0;
+        int k = 0;
+        for (; k + 1 < kend; k += 2) {
+          z0 = fma(Mj[k], r[k], z0);
+          z1 = fma(Mj[k + 1], r[k + 1], z1);
+        }
+        if (k < kend) z0 = fma(Mj[k], r[k], z0);
+        const double z = z0 + z1;
+        q = fma(z, z, q);
+      }
+      out[base + threadIdx.x] = finish_generic(q, ep);
+    }
+  }
+}
+
+bool generic_supported(int d) { return d >= 1 && (size_t)64 * (d | 1) * 8 <= 160 * 1024; }
+
+template <int T>
+static hipError_t launch_t(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+                           const double *M, const double *shift, const double *bias,
+                           const Epilogue &ep, double *out, int num_cus, hipStream_t stream)
+{
+  const size_t lds_bytes = (size_t)T * (d | 1) * sizeof(double);
+  auto kern = logpdf_generic_kernel<T>;
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  const long num_tiles = (N + T - 1) / T;
+  int per_cu = (int)((160 * 1024) / lds_bytes);
+  const int max_per_cu = 2048 / T > 8 ? 8 : 2048 / T;
+  per_cu = per_cu > max_per_cu ? max_per_cu : (per_cu < 1 ? 1 : per_cu);
+  long blocks = (long)num_cus * per_cu;
+  if (blocks > num_tiles) blocks = num_tiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds_bytes, stream, X, (long)N,
+                     (long)ldx, d, (int)tri, M, shift, bias, ep, out, num_tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_logpdf_generic(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+                                 const double *M, const double *shift, const double *bias,
+                                 const Epilogue &ep, double *out, int num_cus, hipStream_t stream)
+{
+  if (N <= 0) return hipSuccess;
+  if (!generic_supported(d)) return hipErrorInvalidValue;
+  const size_t row_bytes = (size_t)(d | 1) * 8;
+  if (256 * row_bytes <= 64 * 1024)
+    return launch_t<256>(X, N, ldx, d, tri, M, shift, bias, ep, out, num_cus, stream);
+  if (128 * row_bytes <= 64 * 1024)
+    return launch_t<128>(X, N, ldx, d, tri, M, shift, bias, ep, out, num_cus, stream);
+  return launch_t<64>(X, N, ldx, d, tri, M, shift, bias, ep, out, num_cus, stream);
+}
+
+}  // namespace cusmc

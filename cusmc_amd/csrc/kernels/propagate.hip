@@ -1,0 +1,175 @@
+// Proposal draws on gfx950: gather + RNG + two mat-vecs in ONE launch.
+//
+// Replaces the reference's four-launch propagate pipeline (mvn_sample_setup_kernel ->
+// mvn_sample_norm_rand_kernel -> mvn_sample_Gmu_kernel -> mvn_sample_kernel,
+// src/mvn_dist.cu.cpp:15-172, host wrapper :175-319 with its AoS<->flat repacking and ten
+// cudaMallocs per call; the mvt twins src/mvt_dist.cu.cpp:63-223) and the CPU loop of propagate_K
+// (src/mcmc.cpp:116-140 -> MultiVariate*Distribution::sample, src/statistics.cc.cpp:224-259,
+// :355-412), and with G == NULL the initial draw of initialize() (src/mcmc.cpp:76-82):
+//
+//     x_out[i] = [diag(c_i)] Q (scale * xi_i) + ( G ? G x_prev[a_i] : m0 )
+//
+// xi_i ~ N(0, I) by Box-Muller on Philox blocks (philox.h: no RNG state array -- the reference
+// keeps 48 bytes of curandState per ELEMENT), c_ij = sqrt(nu / chi2_nu) per component for the
+// Student-t proposal exactly as the reference scales it (src/statistics.cc.cpp:385-386,411;
+// SURVEY.md F7), chi2 by Marsaglia-Tsang as in src/mvt_dist.cu.cpp:20-61 with a deterministic
+// counter advance.
+//
+// Mapping: lane = particle.  The ancestor rows are gathered into LDS with row-coalesced loads,
+// each lane writes its own normals into a second LDS row, then walks the d outputs with Q and G
+// read through wave-uniform (scalar) loads.  Rows are padded to an odd stride (conflict-free
+// ds_read_b64).  This is the general-d first version (d <= 159, limited by two LDS rows per
+// particle); DESIGN.md lists the MFMA formulation as the next step for d >= 32.
+#include <hip/hip_runtime.h>
+
+#include "../launch.h"
+#include "../philox.h"
+#include "../../../include/cusmc_hip.h"
+
+namespace cusmc {
+
+static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, double &z1)
+{
+  const double u1 = 1.0 - u01_53(r.x, r.y);  // (0,1]
+  const double u2 = u01_53(r.z, r.w);        // [0,1)
+  const double rad = sqrt(-2.0 * log(u1));
+  const double ang = 2.0 * 3.14159265358979323846 * u2;
+  z0 = rad * cos(ang);
+  z1 = rad * sin(ang);
+}
+
+// chi^2_nu = 2 Gamma(nu/2, 1); counter layout as oracle/cusmc_oracle.c:chi_square_for.
+static __device__ double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, uint32_t k0,
+                                        uint32_t k1, float nu)
+{
+  double a = 0.5 * (double)nu;
+  double boost = 1.0;
+  if (a < 1.0) {
+    const u32x4 r = philox4x32_10(particle, j * 64u + 63u, step, 5u, k0, k1);
+    boost = pow(1.0 - u01_53(r.x, r.y), 1.0 / a);
+    a += 1.0;
+  }
+  const double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
+  double g = dd;
+  for (uint32_t m = 0; m < 63u; ++m) {
+    double z0, z1;
+    normal_pair(philox4x32_10(particle, j * 64u + m, step, 3u, k0, k1), z0, z1);
+    double v = 1.0 + c * z0;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    const u32x4 r = philox4x32_10(particle, j * 64u + m, step, 5u, k0, k1);
+    const double u = 1.0 - u01_53(r.x, r.y);
+    if (log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) {
+      g = dd * v;
+      break;
+    }
+  }
+  return 2.0 * g * boost;
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void propagate_kernel(
+    int kind, float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
+    const double *__restrict__ G, const double *__restrict__ Q, const double *__restrict__ m0,
+    int d, double scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t domain, uint32_t first,
+    uint32_t count, double *__restrict__ X_out, long num_tiles)
+{
+  extern __shared__ double lds[];
+  const int stride = d | 1;
+  double *sX = lds;                // gathered ancestor rows
+  double *sXi = lds + T * stride;  // this particle's normals
+
+  for (long tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const long base = tile * T;
+    const long rows = ((long)count - base) < T ? ((long)count - base) : T;
+    __syncthreads();
+    if (G) {
+      int row = (int)(threadIdx.x / d), col = (int)(threadIdx.x % d);
+      const int drow = T / d, dcol = T % d;
+      for (long e = threadIdx.x; e < rows * d; e += T) {
+        const uint32_t anc = a ? a[base + row] : first + (uint32_t)(base + row);
+        sX[row * stride + col] = X_prev[(long)anc * d + col];
+        row += drow;
+        col += dcol;
+        if (col >= d) { col -= d; ++row; }
+      }
+    }
+    const uint32_t i = first + (uint32_t)(base + threadIdx.x);
+    double *xi = sXi + threadIdx.x * stride;
+    if ((long)threadIdx.x < rows) {
+      for (int j = 0; j < d; j += 2) {
+        double z0, z1;
+        normal_pair(philox4x32_10(i, (uint32_t)(j >> 1), step, domain, k0, k1), z0, z1);
+        xi[j] = scale * z0;
+        if (j + 1 < d) xi[j + 1] = scale * z1;
+      }
+    }
+    __syncthreads();
+    if ((long)threadIdx.x < rows) {
+      const double *xp = sX + threadIdx.x * stride;
+      double *dst = X_out + (base + threadIdx.x) * d;
+      for (int j = 0; j < d; ++j) {
+        const double *Qj = Q + (long)j * d;
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s = fma(Qj[k], xi[k], s);
+        if (kind == CUSMC_MVT) s *= sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu));
+        double m;
+        if (G) {
+          const double *Gj = G + (long)j * d;
+          m = 0.0;
+          for (int k = 0; k < d; ++k) m = fma(Gj[k], xp[k], m);
+        } else {
+          m = m0[j];
+        }
+        dst[j] = s + m;
+      }
+    }
+  }
+}
+
+template <int T>
+static hipError_t launch_t(int kind, float nu, const double *X_prev, const uint32_t *a,
+                           const double *G, const double *Q, const double *m0, int d,
+                           double scale, uint64_t seed, uint32_t step, uint32_t domain,
+                           uint32_t first, uint32_t count, double *X_out, int num_cus,
+                           hipStream_t stream)
+{
+  const size_t lds_bytes = (size_t)2 * T * (d | 1) * sizeof(double);
+  auto kern = propagate_kernel<T>;
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  const long num_tiles = ((long)count + T - 1) / T;
+  int per_cu = (int)((160 * 1024) / lds_bytes);
+  const int max_per_cu = 2048 / T > 8 ? 8 : 2048 / T;
+  per_cu = per_cu > max_per_cu ? max_per_cu : (per_cu < 1 ? 1 : per_cu);
+  long blocks = (long)num_cus * per_cu;
+  if (blocks > num_tiles) blocks = num_tiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds_bytes, stream, kind, nu, X_prev, a,
+                     G, Q, m0, d, scale, (uint32_t)seed, (uint32_t)(seed >> 32), step, domain,
+                     first, count, X_out, num_tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_propagate(int kind, float nu, const double *X_prev, const uint32_t *a,
+                            const double *G, const double *Q, const double *m0, int d,
+                            double scale, uint64_t seed, uint32_t step, uint32_t domain,
+                            uint32_t first, uint32_t count, double *X_out, int num_cus,
+                            hipStream_t stream)
+{
+  if (count == 0) return hipSuccess;
+  const size_t row_bytes = (size_t)2 * (d | 1) * 8;
+  if (64 * row_bytes > 160 * 1024) return hipErrorInvalidValue;
+  if (256 * row_bytes <= 64 * 1024)
+    return launch_t<256>(kind, nu, X_prev, a, G, Q, m0, d, scale, seed, step, domain, first, count,
+                         X_out, num_cus, stream);
+  if (128 * row_bytes <= 64 * 1024)
+    return launch_t<128>(kind, nu, X_prev, a, G, Q, m0, d, scale, seed, step, domain, first, count,
+                         X_out, num_cus, stream);
+  return launch_t<64>(kind, nu, X_prev, a, G, Q, m0, d, scale, seed, step, domain, first, count,
+                      X_out, num_cus, stream);
+}
+
+}  // namespace cusmc

@@ -1,0 +1,56 @@
+// Host-callable launchers of the gfx950 kernels (one per .hip file under kernels/).
+// Internal to libcusmc_hip.so; the public surface is include/cusmc_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cusmc {
+
+// Epilogue of the quadratic form q = |z|^2:
+//   mvn: lognorm - q/2                              (src/statistics.cc.cpp:179, as a log)
+//   mvt: lognorm - (nu+d)/2 * log1p(q/nu)           (src/statistics.cc.cpp:308-310, as a log)
+struct Epilogue {
+  double lognorm;
+  double half_nu_plus_d;  // mvt only
+  double inv_nu;          // mvt only
+  int kind;               // CUSMC_MVN / CUSMC_MVT
+  int out_density;        // exponentiate at the end
+};
+
+// Every log-pdf kernel computes, per particle x (d doubles):
+//     z = bias + M (x - shift),   q = z.z,   out = epilogue(q)
+// centred form  (pdf(y,F)):   M = W = L^-1 (lower triangular), shift = F mu, bias = 0
+// affine form   (reweight_G): M = -W F (dense),                shift = 0,    bias = W y
+
+// --- kernels/logpdf_mfma.hip : d = 16*NB, v_mfma_f64_16x16x4_f64 -------------------------------
+// Number of 512-byte B fragments the kernel expects in `frags` (LDS image, kernel loop order).
+int mfma_num_frags(int nb, bool tri);
+// Is (d, X, ldx) servable by the MFMA kernel?
+bool mfma_supported(int d, const void *X, int64_t ldx);
+// Host-side packing of M (d x d row-major) into the fragment order.
+void mfma_pack_frags(const double *M, int d, bool tri, double *frags);
+hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+                              const double *frags, const double *shift, const double *bias,
+                              const Epilogue &ep, double *out, int num_cus, hipStream_t stream);
+
+// --- kernels/logpdf_generic.hip : any d <= 319, lane = particle --------------------------------
+bool generic_supported(int d);
+hipError_t launch_logpdf_generic(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+                                 const double *M, const double *shift, const double *bias,
+                                 const Epilogue &ep, double *out, int num_cus,
+                                 hipStream_t stream);
+
+// --- kernels/resample.hip ------------------------------------------------------------------------
+hipError_t launch_metropolis(const double *w, uint32_t N, uint32_t B, uint64_t seed,
+                             uint32_t step, uint32_t first, uint32_t count, uint32_t *a,
+                             int num_cus, hipStream_t stream);
+
+// --- kernels/propagate.hip -----------------------------------------------------------------------
+// X_out[i-first] = [diag(c)] Q (scale xi) + (G ? G X_prev[a ? a[i-first] : i] : m0)
+hipError_t launch_propagate(int kind, float nu, const double *X_prev, const uint32_t *a,
+                            const double *G, const double *Q, const double *m0, int d,
+                            double scale, uint64_t seed, uint32_t step, uint32_t domain,
+                            uint32_t first, uint32_t count, double *X_out, int num_cus,
+                            hipStream_t stream);
+
+}  // namespace cusmc

@@ -1,0 +1,168 @@
+/*
+ * cusmc_hip.h -- C ABI of libcusmc_hip.so: the MI355X (gfx950) implementation of CuSMC's
+ * per-particle likelihood / proposal / accept-reject hot path.
+ *
+ * This is the lower drop-in boundary.  The reference has no C ABI of its
+ * own; its nearest analogue is the five C++ device-wrapper prototypes in
+ * inst/include/distributions/mvn_dist.hpp:19-54 (Eigen arguments, void return, death via
+ * FATAL/Rcpp::stop, inst/include/support.cuh:9-32).  Each entry point below names the
+ * reference interface it stands in for.  The Rcpp glue that binds these to the six registered
+ * R symbols (src/RcppExports.cpp:105-113) is in rcpp/src; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - Every function returns an int status: CUSMC_OK (0) or a CUSMC_E* code; the text of the
+ *     last failure on the calling thread is cusmc_last_error().  No exception crosses the ABI.
+ *   - Plain pointers and sizes only.  `_dev` arguments are device pointers on the context's
+ *     GPU; everything else is host memory owned by the caller.  Opaque handles own device
+ *     memory and must be destroyed by the caller.
+ *   - All arithmetic is fp64.  Matrices are dense ROW-major, M[i*d+j] (an Eigen column-major
+ *     matrix is passed as its transpose: see rcpp/src/glue.hpp).  Particle batches are N x d
+ *     row-major with leading dimension ldx >= d: each particle's d doubles contiguous -- for an
+ *     R `d x N` matrix (columns = particles, src/run.rcpp.cpp:91) that is the buffer as it is.
+ *   - nu is a C float, as in the reference (inst/include/statistics.hpp:30,199).
+ *   - Work is enqueued on the context's HIP stream; `_dev` calls return without waiting
+ *     (use cusmc_ctx_synchronize), `_host` calls return when the output buffer is filled.
+ *   - One context per host thread (thread-compatible, not thread-safe) -- all R needs.
+ *   - RNG: counter-based Philox4x32-10, key = seed, counter = (index, sub, step, domain); the
+ *     full contract is in DESIGN.md section "RNG contract" and restated in oracle/cusmc_oracle.c.
+ */
+#ifndef CUSMC_HIP_H
+#define CUSMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUSMC_OK 0
+#define CUSMC_EINVAL 1    /* bad argument (NULL, d <= 0, ldx < d, unknown option string ...) */
+#define CUSMC_ENOTSPD 2   /* covariance / scale matrix is not symmetric positive definite   */
+#define CUSMC_EHIP 3      /* a HIP runtime call failed (text in cusmc_last_error)           */
+#define CUSMC_ENODEVICE 4 /* no usable gfx950 device                                          */
+#define CUSMC_ERANGE 5    /* size beyond what the kernels support (d > CUSMC_MAX_DIM ...)    */
+
+#define CUSMC_MAX_DIM 256
+
+/* distribution kinds -- the keys of the reference's Distributions registry
+ * ("mvn", "mvt": src/mcmc.cpp:53-58) */
+#define CUSMC_MVN 0
+#define CUSMC_MVT 1
+
+/* output flags for the density entry points */
+#define CUSMC_OUT_LOG 0     /* log-density (the build's internal quantity)                  */
+#define CUSMC_OUT_DENSITY 1 /* density, what the reference returns (statistics.cc.cpp:179) */
+
+typedef struct cusmc_ctx cusmc_ctx;   /* device + stream + scratch                            */
+typedef struct cusmc_dist cusmc_dist; /* a StatisticalDistribution instance (mu, Sigma[, nu]) */
+
+/* ---- library / context ---------------------------------------------------------------- */
+
+const char *cusmc_version(void);
+const char *cusmc_last_error(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int cusmc_device_count(void);
+
+/* device < 0: keep the calling thread's current device.  The reference has no context: it
+ * uses device 0 / the default stream implicitly and cudaDeviceReset()s after each call
+ * (src/mvn_dist.cu.cpp:788). */
+int cusmc_ctx_create(int device, cusmc_ctx **out);
+int cusmc_ctx_destroy(cusmc_ctx *ctx);
+/* Adopt a caller-owned hipStream_t (NULL = the default stream). */
+int cusmc_ctx_set_stream(cusmc_ctx *ctx, void *hip_stream);
+int cusmc_ctx_synchronize(cusmc_ctx *ctx);
+/* multiProcessorCount of the context's device. */
+int cusmc_ctx_num_cus(cusmc_ctx *ctx, int *out);
+
+/* ---- distributions: MultiVariateNormalDistribution / MultiVariateTStudentDistribution ---
+ * getInstance(params) -- src/statistics.cc.cpp:164-168, :288-292.  Factors Sigma once
+ * (Cholesky, W = L^-1, log det) and uploads the factor in the kernels' fragment order.
+ * mu may be NULL (zero mean, as reweight_G sets it: src/mcmc.cpp:188).  nu ignored for MVN. */
+int cusmc_dist_create(cusmc_ctx *ctx, int kind, const double *mu, const double *sigma, int d,
+                      float nu, cusmc_dist **out);
+int cusmc_dist_destroy(cusmc_dist *dist);
+
+/* getNorm() -- src/statistics.cc.cpp:205-211 (mvn), :332-340 (mvt); returned as a log. */
+int cusmc_dist_lognorm(const cusmc_dist *dist, double *out);
+int cusmc_dist_logdet(const cusmc_dist *dist, double *out);
+
+/* Batched pdf(y, F) -- src/statistics.cc.cpp:183-196 (mvn), :295-311 (mvt):
+ *     out[i] = log p( X[i,:] ;  F mu, Sigma )            r_i = x_i - F mu
+ * F == NULL means the identity (what MVNPDF()/MVTPDF() pass: src/mvn_dist.rcpp.cpp:55,
+ * src/mvt_dist.rcpp.cpp:64). */
+int cusmc_dist_pdf_dev(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx,
+                       const double *F, int flags, double *out_dev);
+int cusmc_dist_pdf_host(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx,
+                        const double *F, int flags, double *out);
+
+/* reweight_G -- src/mcmc.cpp:162-237 (the pdf(y) overload, :171-180 / :313-324, applied to
+ * y_t - F x_i; replaces mvn_pdf_kernel_wrapper / mvt_pdf_kernel_wrapper,
+ * inst/include/distributions/mvn_dist.hpp:19-27,38-46):
+ *     out[i] = log p( y - F X[i,:] ;  0, Sigma )
+ * The distribution's own mu is not used (the reference sets it to zero there). */
+int cusmc_dist_reweight_dev(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx,
+                            const double *y, const double *F, int flags, double *out_dev);
+int cusmc_dist_reweight_host(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx,
+                             const double *y, const double *F, int flags, double *out);
+
+/* ---- Metropolis resampler: Sampler::metropolis_hastings -- src/samplers.cpp:7-36 ----------
+ * For each i in [first, first+count):  k = i; repeat B times { u ~ U[0,1); j ~ UnifInt[0,N);
+ * if (u <= w[j] / w[k]) k = j; }  a[i-first] = k.      (0-based ancestors, as the reference.)
+ * w has N entries (the full weight vector); [first, first+count) is this caller's shard of
+ * the output (first = 0, count = N on one GPU).  `step` is the reference's t. */
+int cusmc_metropolis_dev(cusmc_ctx *ctx, const double *w_dev, uint32_t N, uint32_t B,
+                         uint64_t seed, uint32_t step, uint32_t first, uint32_t count,
+                         uint32_t *a_dev);
+int cusmc_metropolis_host(cusmc_ctx *ctx, const double *w, uint32_t N, uint32_t B, uint64_t seed,
+                          uint32_t step, uint32_t *a);
+
+/* ---- proposal draws ------------------------------------------------------------------------
+ * propagate_K -- src/mcmc.cpp:90-160 (replaces mvn_sample_kernel_wrapper /
+ * mvt_sample_kernel_wrapper, mvn_dist.hpp:29-32,48-54):
+ *     x_t[i] = [diag(c_i)] Q (scale * xi_i) + G x_prev[a[i]],   xi_i ~ N(0, I)
+ * c_i,j = sqrt(nu / chi2_nu) per component for kind == CUSMC_MVT (src/statistics.cc.cpp:385-386,
+ * 411).  Q is the dense square-root factor the caller supplies (eigenSolver:
+ * src/linear_algebra.cpp:10-23, or cusmc_eigen_sqrt below).  scale = 1 draws from N(mu, QQ^T);
+ * scale = sqrt(3) reproduces the distribution of the reference's CPU transform
+ * (src/statistics.cc.cpp:245-256).  a_dev == NULL means a[i] = i.
+ * Rows [first, first+count) of the output are produced (X_out_dev has `count` rows); X_prev
+ * has N rows. */
+int cusmc_propagate_dev(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev,
+                        const uint32_t *a_dev, uint32_t N, int d, const double *G,
+                        const double *Q, double scale, uint64_t seed, uint32_t step,
+                        uint32_t first, uint32_t count, double *X_out_dev);
+
+/* initialize() draws -- src/mcmc.cpp:44-88 (replaces mvn_sample_kernel_wrapper(init),
+ * mvn_dist.hpp:34-37):   x_0[i] = [diag(c_i)] Q (scale * xi_i) + m0 */
+int cusmc_initialize_dev(cusmc_ctx *ctx, int kind, float nu, const double *m0, const double *Q,
+                         int d, double scale, uint64_t seed, uint32_t first, uint32_t count,
+                         double *X_out_dev);
+
+/* StatisticalDistribution::sample(draws, Q, n_iter) as the R-level MVN()/MVT() call it
+ * (src/mvn_dist.rcpp.cpp:31-37, src/mvt_dist.rcpp.cpp:28-49), batched: `count` draws
+ *     X_out[i] = [diag(c_i)] Q (scale * xi_i) + mu,   index = i, counter step = `step`
+ * into host memory (count x d row-major). */
+int cusmc_sample_host(cusmc_ctx *ctx, int kind, float nu, const double *mu, const double *Q, int d,
+                      double scale, uint64_t seed, uint32_t step, uint32_t count, double *X_out);
+
+/* eigenSolver -- src/linear_algebra.cpp:10-23:  Q = V sqrt(Lambda), Q Q^T = sigma.  Host only. */
+int cusmc_eigen_sqrt(const double *sigma, int d, double *Q);
+
+/* ---- the filter: particle_filter() -- src/particle_filter.cpp:6-39, MCMC() mcmc.cpp:239-309 -
+ * Device-resident time loop: initialize, then for t = 1..T-1: resample(w_{t-1}) -> propagate
+ * -> reweight.  Y is T x d (row t = y_t; the reference stores Y.col(t): run.rcpp.cpp:91).
+ * Outputs (host, any may be NULL): X T x N x d, w T x N (densities, unnormalised, as
+ * run.rcpp.cpp:110-116 returns them), a T x N (row 0 unwritten in the reference; zeros here).
+ * resampler must be "metropolis", distribution "mvn" or "mvt" (mcmc.cpp:252-266); anything
+ * else is CUSMC_EINVAL (the reference throws bad_function_call). */
+int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T,
+                      const double *m0, const double *C0, const double *F, const double *G,
+                      const double *V, const double *W, float df, const char *resampler,
+                      const char *distribution, uint32_t B, double scale, uint64_t seed,
+                      double *X_out, double *w_out, uint32_t *a_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUSMC_HIP_H */

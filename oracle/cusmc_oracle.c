@@ -1,0 +1,574 @@
+/*
+ * cusmc_oracle.c -- CPU restatement of CuSMC's per-particle likelihood / proposal /
+ * accept-reject hot path.  Plain C11 + OpenMP, no Eigen, no R.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call it.  The shipped path
+ * (cusmc_amd/csrc -> libcusmc_hip.so) never links or calls anything in oracle/.
+ *
+ * Parity status
+ *   - pdf / getNorm : pinned by the reference's three published known answers
+ *     (CuSMC/CuSMC.tex:95-105, :131-142; man/metropolis_hastings.Rd:22-27) and cross-checked
+ *     against scipy.stats (tests/golden/make_golden.py).  The reference has no other fixtures
+ *     (SURVEY.md F11), and its C++ cannot be compiled here (every TU includes <RcppEigen.h>;
+ *     no R / Rcpp / Eigen in the image), so beyond those three values: PARITY UNPINNED.
+ *   - RNG-driven functions (resampler, draws): the reference seeds from std::random_device
+ *     on every call (src/samplers.cpp:10-11, src/statistics.cc.cpp:231-232) and cannot be
+ *     reproduced by anyone.  This file defines the build's counter-based contract
+ *     (Philox4x32-10, pinned by the Random123 known-answer vectors) that the HIP kernels
+ *     must match bit-for-bit on index sequences.
+ *
+ * Conventions: all matrices are dense row-major double, M[i*n+j].  Particle batches are
+ * N x d row-major with leading dimension ldx (each particle's d doubles contiguous), the
+ * flat layout the reference's own device wrappers build (src/mvn_dist.cu.cpp:722-737).
+ * nu is a C float end to end, as in the reference (inst/include/statistics.hpp:30,199).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * Dense LU with partial pivoting: what Eigen's MatrixXd::determinant() / ::inverse() do for a
+ * dynamic-size matrix (PartialPivLU).  Call sites being restated:
+ * src/statistics.cc.cpp:176-177,190,193,301,306,317,320.
+ * ---------------------------------------------------------------------------------------- */
+static int lu_factor(double *A, int *piv, int n, int *sign)
+{
+  *sign = 1;
+  int singular = 0;
+  for (int k = 0; k < n; ++k) {
+    int p = k;
+    double best = fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; ++i) {
+      double v = fabs(A[i * n + k]);
+      if (v > best) { best = v; p = i; }
+    }
+    piv[k] = p;
+    if (p != k) {
+      for (int j = 0; j < n; ++j) {
+        double tmp = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = tmp;
+      }
+      *sign = -*sign;
+    }
+    double pivot = A[k * n + k];
+    if (pivot == 0.0) { singular = 1; continue; }
+    for (int i = k + 1; i < n; ++i) {
+      double l = A[i * n + k] / pivot;
+      A[i * n + k] = l;
+      for (int j = k + 1; j < n; ++j) A[i * n + j] -= l * A[k * n + j];
+    }
+  }
+  return singular;
+}
+
+ORACLE_API double oracle_det(const double *S, int n)
+{
+  double *A = (double *)malloc(sizeof(double) * n * n);
+  int *piv = (int *)malloc(sizeof(int) * n);
+  int sign;
+  memcpy(A, S, sizeof(double) * n * n);
+  lu_factor(A, piv, n, &sign);
+  double det = (double)sign;
+  for (int i = 0; i < n; ++i) det *= A[i * n + i];
+  free(A); free(piv);
+  return det;
+}
+
+ORACLE_API int oracle_inverse(const double *S, double *inv, int n)
+{
+  double *A = (double *)malloc(sizeof(double) * n * n);
+  int *piv = (int *)malloc(sizeof(int) * n);
+  double *col = (double *)malloc(sizeof(double) * n);
+  int sign;
+  memcpy(A, S, sizeof(double) * n * n);
+  int singular = lu_factor(A, piv, n, &sign);
+  for (int c = 0; c < n; ++c) {
+    for (int i = 0; i < n; ++i) col[i] = (i == c) ? 1.0 : 0.0;
+    for (int k = 0; k < n; ++k) { /* apply row swaps */
+      int p = piv[k];
+      if (p != k) { double t = col[k]; col[k] = col[p]; col[p] = t; }
+    }
+    for (int i = 0; i < n; ++i) { /* L y = Pb */
+      double s = col[i];
+      for (int j = 0; j < i; ++j) s -= A[i * n + j] * col[j];
+      col[i] = s;
+    }
+    for (int i = n - 1; i >= 0; --i) { /* U x = y */
+      double s = col[i];
+      for (int j = i + 1; j < n; ++j) s -= A[i * n + j] * col[j];
+      col[i] = s / A[i * n + i];
+    }
+    for (int i = 0; i < n; ++i) inv[i * n + c] = col[i];
+  }
+  free(A); free(piv); free(col);
+  return singular;
+}
+
+/* r = y - F*mu  (F may be NULL: the pdf(y) overload, where the caller folded the mean). */
+static void residual(const double *y, const double *mu, const double *F, int n, double *r)
+{
+  for (int i = 0; i < n; ++i) {
+    double s = 0.0;
+    if (F) { for (int j = 0; j < n; ++j) s += F[i * n + j] * mu[j]; }
+    r[i] = F ? (y[i] - s) : y[i];
+  }
+}
+
+/* (r^T * Sinv) * r, left-associated like the Eigen expression
+ * `y.transpose() * sigma.inverse() * y` (src/statistics.cc.cpp:177,193). */
+static double quadform(const double *r, const double *Sinv, int n)
+{
+  double q = 0.0;
+  for (int j = 0; j < n; ++j) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += r[i] * Sinv[i * n + j];
+    q += s * r[j];
+  }
+  return q;
+}
+
+/* MultiVariateNormalDistribution::getNorm -- src/statistics.cc.cpp:205-211 */
+ORACLE_API double oracle_mvn_norm(const double *sigma, int n)
+{
+  const double sqrt2pi = sqrt(2 * M_PI);
+  return 1.0 / (pow(sqrt2pi, (double)n) * pow(oracle_det(sigma, n), 0.5));
+}
+
+/* MultiVariateNormalDistribution::pdf(y, F) -- src/statistics.cc.cpp:183-196;
+ * with F == NULL the pdf(y) overload, :171-180.  Determinant and inverse are recomputed on
+ * every call, exactly as the reference does. */
+ORACLE_API double oracle_mvn_pdf(const double *y, const double *mu, const double *sigma,
+                                 const double *F, int n)
+{
+  double *inv = (double *)malloc(sizeof(double) * n * n);
+  double *r = (double *)malloc(sizeof(double) * n);
+  double norm = oracle_mvn_norm(sigma, n);
+  oracle_inverse(sigma, inv, n);
+  residual(y, mu, F, n, r);
+  double q = quadform(r, inv, n);
+  free(inv); free(r);
+  return norm * exp(-0.5 * q);
+}
+
+/* MultiVariateTStudentDistribution::getNorm -- src/statistics.cc.cpp:332-340.
+ * `nu + n` is float arithmetic in the reference (float + unsigned). */
+ORACLE_API double oracle_mvt_norm(const double *sigma, int n, float nu)
+{
+  double pixdf = M_PI * (double)nu;
+  double norm1 = pow(pixdf, -0.5 * (double)n) * pow(oracle_det(sigma, n), -0.5);
+  float nu_plus_n = nu + (float)n;
+  double norm2 = tgamma(0.5 * (double)nu_plus_n) / tgamma(0.5 * (double)nu);
+  return norm1 * norm2;
+}
+
+/* MultiVariateTStudentDistribution::pdf(y, F) / pdf(y) -- src/statistics.cc.cpp:295-324 */
+ORACLE_API double oracle_mvt_pdf(const double *y, const double *mu, const double *sigma,
+                                 const double *F, int n, float nu)
+{
+  double *inv = (double *)malloc(sizeof(double) * n * n);
+  double *r = (double *)malloc(sizeof(double) * n);
+  double norm = oracle_mvt_norm(sigma, n, nu);
+  oracle_inverse(sigma, inv, n);
+  residual(y, mu, F, n, r);
+  double q1 = quadform(r, inv, n);
+  double q = 1.0 + pow((double)nu, -1.0) * q1;
+  float nu_plus_n = nu + (float)n;
+  free(inv); free(r);
+  return norm * pow(q, -0.5 * (double)nu_plus_n);
+}
+
+/* Batched, reference-faithful: one fresh distribution + LU det + LU inverse PER PARTICLE,
+ * OpenMP parallel-for over particles -- the cost structure of reweight_G's CPU branch
+ * (src/mcmc.cpp:193-215) and of R-level MVNPDF/MVTPDF applied particle by particle.
+ * dist: 0 = mvn, 1 = mvt.  F may be NULL (identity / pre-folded). */
+ORACLE_API void oracle_pdf_batch(const double *X, long N, long ldx, const double *mu,
+                                 const double *sigma, const double *F, int n, int dist, float nu,
+                                 double *out)
+{
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < N; ++i) {
+    out[i] = dist ? oracle_mvt_pdf(X + i * ldx, mu, sigma, F, n, nu)
+                  : oracle_mvn_pdf(X + i * ldx, mu, sigma, F, n);
+  }
+}
+
+/* reweight_G, CPU branch -- src/mcmc.cpp:185-215:
+ *   w[i] = pdf_{0,V}( y - F * x_i )     (the pdf(y) overload, mean zero) */
+ORACLE_API void oracle_reweight(const double *X, long N, long ldx, const double *y,
+                                const double *F, const double *V, int n, int dist, float nu,
+                                double *w)
+{
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < N; ++i) {
+    double *r = (double *)malloc(sizeof(double) * n);
+    const double *x = X + i * ldx;
+    for (int a = 0; a < n; ++a) {
+      double s = 0.0;
+      for (int b = 0; b < n; ++b) s += F[a * n + b] * x[b];
+      r[a] = y[a] - s;
+    }
+    w[i] = dist ? oracle_mvt_pdf(r, NULL, V, NULL, n, nu) : oracle_mvn_pdf(r, NULL, V, NULL, n);
+    free(r);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Hoisted-factor form (factor Sigma once, triangular solve per particle).  Not how the
+ * reference spends its time, but the same function of the inputs; used (i) as the second CPU
+ * baseline line that separates algorithmic gain from hardware gain and
+ * (ii) as the checker at sizes where the O(N d^3) faithful form is too slow.
+ * ---------------------------------------------------------------------------------------- */
+ORACLE_API int oracle_cholesky(const double *S, double *L, int n)
+{
+  memset(L, 0, sizeof(double) * n * n);
+  for (int j = 0; j < n; ++j) {
+    double s = S[j * n + j];
+    for (int k = 0; k < j; ++k) s -= L[j * n + k] * L[j * n + k];
+    if (!(s > 0.0)) return j + 1;
+    double ljj = sqrt(s);
+    L[j * n + j] = ljj;
+    for (int i = j + 1; i < n; ++i) {
+      double t = S[i * n + j];
+      for (int k = 0; k < j; ++k) t -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = t / ljj;
+    }
+  }
+  return 0;
+}
+
+/* dist 0: log N(x; mu, Sigma);  dist 1: log t_nu(x; mu, Sigma).  F NULL => r = x - mu,
+ * else r = x - F mu (pdf(y,F) semantics).  Returns nonzero if Sigma is not SPD. */
+ORACLE_API int oracle_logpdf_hoisted(const double *X, long N, long ldx, const double *mu,
+                                     const double *sigma, const double *F, int n, int dist,
+                                     float nu, double *out)
+{
+  double *L = (double *)malloc(sizeof(double) * n * n);
+  double *m = (double *)malloc(sizeof(double) * n);
+  int rc = oracle_cholesky(sigma, L, n);
+  if (rc) { free(L); free(m); return rc; }
+  double logdet = 0.0;
+  for (int i = 0; i < n; ++i) logdet += 2.0 * log(L[i * n + i]);
+  for (int i = 0; i < n; ++i) {
+    double s = 0.0;
+    if (F) { for (int j = 0; j < n; ++j) s += F[i * n + j] * mu[j]; } else s = mu ? mu[i] : 0.0;
+    m[i] = s;
+  }
+  float nu_plus_n = nu + (float)n;
+  double lognorm;
+  if (dist == 0)
+    lognorm = -0.5 * ((double)n * log(2 * M_PI) + logdet);
+  else
+    lognorm = lgamma(0.5 * (double)nu_plus_n) - lgamma(0.5 * (double)nu) -
+              0.5 * (double)n * log(M_PI * (double)nu) - 0.5 * logdet;
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < N; ++i) {
+    double z[n];
+    const double *x = X + i * ldx;
+    double q = 0.0;
+    for (int a = 0; a < n; ++a) {
+      double s = x[a] - m[a];
+      for (int b = 0; b < a; ++b) s -= L[a * n + b] * z[b];
+      z[a] = s / L[a * n + a];
+      q += z[a] * z[a];
+    }
+    out[i] = dist ? lognorm - 0.5 * (double)nu_plus_n * log1p(q / (double)nu) : lognorm - 0.5 * q;
+  }
+  free(L); free(m);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Counter-based RNG contract of the build: Philox4x32-10 (Salmon et al.,
+ * SC'11; Random123).  Pinned by the Random123 known-answer vectors in tests/test_oracle.py.
+ *   key     = (seed_lo, seed_hi)
+ *   counter = (index, sub, step, domain)
+ * domain tags: 1 resampler, 2 proposal normals, 3 chi-square normals, 4 initial normals,
+ *              5 chi-square accept/boost uniforms.
+ * ---------------------------------------------------------------------------------------- */
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+ORACLE_API void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+    uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += PHILOX_W0; k1 += PHILOX_W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* 53-bit uniform in [0,1) from two words, and an unbiased-to-2^-64 integer in [0,N). */
+static inline double u01_53(uint32_t hi, uint32_t lo)
+{
+  uint64_t v = ((uint64_t)hi << 32) | lo;
+  return (double)(v >> 11) * 0x1.0p-53;
+}
+static inline uint32_t uint_below(uint32_t hi, uint32_t lo, uint32_t N)
+{
+  uint64_t v = ((uint64_t)hi << 32) | lo;
+  return (uint32_t)(((unsigned __int128)v * (unsigned __int128)N) >> 64);
+}
+
+/* Sampler::metropolis_hastings -- src/samplers.cpp:7-36, inner loop :21-35.
+ * Per particle i: k = i; repeat B times: u ~ U[0,1) THEN j ~ UnifInt{0..N-1} (that draw
+ * order); accept iff (u <= w[j] / w[k]) -- the same division and <=, so a NaN ratio never
+ * accepts (man/metropolis_hastings.Rd:22-27).  u, j, k are thread-private here (the
+ * reference's shared declarations are a data race).
+ * One Philox block per (i, n): words 0,1 -> u; words 2,3 -> j.
+ * `step` plays the role of the reference's t (a_t[t*N+i] = k); the caller owns the offset. */
+ORACLE_API void oracle_metropolis(uint32_t *a, const double *w, uint32_t N, uint32_t B,
+                                  uint64_t seed, uint32_t step)
+{
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < N; ++i) {
+    uint32_t k = i;
+    double wk = w[k];
+    for (uint32_t n = 0; n < B; ++n) {
+      uint32_t ctr[4] = {i, n, step, 1u}, r[4];
+      oracle_philox4x32_10(ctr, key, r);
+      double u = u01_53(r[0], r[1]);
+      uint32_t j = uint_below(r[2], r[3], N);
+      double wj = w[j];
+      if (u <= wj / wk) { k = j; wk = wj; }
+    }
+    a[i] = k;
+  }
+}
+
+/* Standard-normal pair by Box-Muller from one Philox block: u1 in (0,1], u2 in [0,1). */
+static inline void normal_pair(const uint32_t r[4], double *z0, double *z1)
+{
+  double u1 = 1.0 - u01_53(r[0], r[1]);
+  double u2 = u01_53(r[2], r[3]);
+  double rad = sqrt(-2.0 * log(u1));
+  double ang = 2.0 * M_PI * u2;
+  *z0 = rad * cos(ang);
+  *z1 = rad * sin(ang);
+}
+
+/* xi_j, j < d, for (particle, step): block (index=particle, sub=j/2, step, domain). */
+static void normals_for(uint32_t particle, uint32_t step, uint32_t domain, const uint32_t key[2],
+                        int d, double *xi)
+{
+  for (int j = 0; j < d; j += 2) {
+    uint32_t ctr[4] = {particle, (uint32_t)(j >> 1), step, domain}, r[4];
+    double z0, z1;
+    oracle_philox4x32_10(ctr, key, r);
+    normal_pair(r, &z0, &z1);
+    xi[j] = z0;
+    if (j + 1 < d) xi[j + 1] = z1;
+  }
+}
+
+/* chi^2_nu = 2 * Gamma(nu/2, 1), Marsaglia-Tsang squeeze with the a<1 boost, the sampler the
+ * reference's device helper uses (src/mvt_dist.cu.cpp:20-61; the CPU path uses libstdc++'s
+ * chi_squared_distribution, src/statistics.cc.cpp:366,385).  The counter advance is
+ * deterministic: attempt m < 63 of (particle, component j) takes its normal from block
+ * (particle, j*64+m, step, 3) and its accept-uniform from block (particle, j*64+m, step, 5);
+ * the a<1 boost uniform is block (particle, j*64+63, step, 5). */
+static double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, const uint32_t key[2],
+                             float nu)
+{
+  double a = 0.5 * (double)nu;
+  double boost = 1.0;
+  if (a < 1.0) {
+    uint32_t ctr[4] = {particle, j * 64u + 63u, step, 5u}, r[4];
+    oracle_philox4x32_10(ctr, key, r);
+    boost = pow(1.0 - u01_53(r[0], r[1]), 1.0 / a);
+    a += 1.0;
+  }
+  double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
+  double g = dd; /* value if all 63 attempts reject (probability < 1e-60) */
+  for (uint32_t m = 0; m < 63u; ++m) {
+    uint32_t ctr[4] = {particle, j * 64u + m, step, 3u}, r[4];
+    double z0, z1;
+    oracle_philox4x32_10(ctr, key, r);
+    normal_pair(r, &z0, &z1);
+    double v = 1.0 + c * z0;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    ctr[3] = 5u;
+    oracle_philox4x32_10(ctr, key, r);
+    double u = 1.0 - u01_53(r[0], r[1]);
+    if (log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) { g = dd * v; break; }
+  }
+  return 2.0 * g * boost;
+}
+
+/* One proposal draw given the location m (d) and the square-root factor Q (d x d, dense).
+ *   mvn:  x = Q xi + m                                  src/statistics.cc.cpp:258
+ *   mvt:  x = diag(c) (Q xi) + m,  c_j = sqrt(nu/chi2)  src/statistics.cc.cpp:385-386,411
+ * xi ~ N(0, s^2 I).  s = 1 is the statistically correct draw (what the reference's device
+ * path does, src/mvn_dist.cu.cpp:24-31); s = sqrt(3) ("clt_compat") is the distribution the
+ * reference's CPU path actually produces: (sum_{i<200} (z_i+1)/2 - 100)/sqrt(200/12) is
+ * exactly N(0,3) (src/statistics.cc.cpp:245-256). */
+static void draw_one(uint32_t particle, uint32_t step, uint32_t domain, const uint32_t key[2],
+                     const double *m, const double *Q, int d, int dist, float nu, double scale,
+                     double *x)
+{
+  double xi[d];
+  normals_for(particle, step, domain, key, d, xi);
+  for (int a = 0; a < d; ++a) {
+    double s = 0.0;
+    for (int b = 0; b < d; ++b) s += Q[a * d + b] * (scale * xi[b]);
+    if (dist) {
+      double chi = chi_square_for(particle, (uint32_t)a, step, key, nu);
+      s *= sqrt((double)nu / chi);
+    }
+    x[a] = s + m[a];
+  }
+}
+
+/* initialize() -- src/mcmc.cpp:44-88:  x_0[i] ~ dist(m0).sample(Q0);  w_0 = 1/N.
+ * The filter uses step = 0; the R-level MVN()/MVT() draws (src/mvn_dist.rcpp.cpp:31-37,
+ * src/mvt_dist.rcpp.cpp:28-49) are the same transform with a per-call step. */
+ORACLE_API void oracle_initialize(double *X0, double *w0, uint32_t N, int d, const double *m0,
+                                  const double *Q0, int dist, float nu, double scale,
+                                  uint64_t seed, uint32_t step)
+{
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < N; ++i) {
+    draw_one(i, step, 4u, key, m0, Q0, d, dist, nu, scale, X0 + (size_t)i * d);
+    w0[i] = 1.0 / (double)N;
+  }
+}
+
+/* propagate_K(), CPU branch -- src/mcmc.cpp:112-140:
+ *   mu_i = G * x_{t-1}[a_i];   x_t[i] ~ dist(mu_i).sample(Q_w) */
+ORACLE_API void oracle_propagate(double *Xt, const double *Xprev, const uint32_t *a, uint32_t N,
+                                 int d, const double *G, const double *Qw, int dist, float nu,
+                                 double scale, uint64_t seed, uint32_t step)
+{
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < N; ++i) {
+    double m[d];
+    const double *xp = Xprev + (size_t)a[i] * d;
+    for (int r = 0; r < d; ++r) {
+      double s = 0.0;
+      for (int c = 0; c < d; ++c) s += G[r * d + c] * xp[c];
+      m[r] = s;
+    }
+    draw_one(i, step, 2u, key, m, Qw, d, dist, nu, scale, Xt + (size_t)i * d);
+  }
+}
+
+/* Symmetric eigen square root Q = V sqrt(Lambda) -- src/linear_algebra.cpp:10-23.
+ * Cyclic Jacobi.  Q Q^T = Sigma; column order / signs are not unique (nor are Eigen's). */
+ORACLE_API void oracle_eigen_sqrt(const double *S, double *Q, int n)
+{
+  double *A = (double *)malloc(sizeof(double) * n * n);
+  double *V = (double *)malloc(sizeof(double) * n * n);
+  memcpy(A, S, sizeof(double) * n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        double apq = A[p * n + q];
+        if (apq == 0.0) continue;
+        double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - s * akq;
+          A[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - s * aqk;
+          A[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - s * vkq;
+          V[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double lam = A[j * n + j];
+      Q[i * n + j] = V[i * n + j] * sqrt(lam > 0.0 ? lam : 0.0);
+    }
+  free(A); free(V);
+}
+
+/* MCMC() time loop -- src/mcmc.cpp:239-309, loop :292-308, with initialize() in front as
+ * particle_filter() does (src/particle_filter.cpp:22-36).  B = 10 is the reference's
+ * hard-coded value (mcmc.cpp:291) but is a parameter here.
+ *   X : T x N x d,  W : T x N (unnormalised pdf values, as the reference stores them),
+ *   A : T x N ancestors (row 0 never written, as in the reference), Y : T x d (row t = y_t).
+ * hoisted != 0 evaluates weights through the Cholesky form instead of per-particle LU. */
+ORACLE_API int oracle_pf_run(double *X, double *W, uint32_t *A, const double *Y, uint32_t N,
+                             int d, uint32_t T, const double *m0, const double *C0,
+                             const double *F, const double *G, const double *V, const double *Wc,
+                             int dist, float nu, uint32_t B, double scale, uint64_t seed,
+                             int hoisted)
+{
+  double *Q0 = (double *)malloc(sizeof(double) * d * d);
+  double *Qw = (double *)malloc(sizeof(double) * d * d);
+  oracle_eigen_sqrt(C0, Q0, d);
+  oracle_eigen_sqrt(Wc, Qw, d);
+  oracle_initialize(X, W, N, d, m0, Q0, dist, nu, scale, seed, 0u);
+  int rc = 0;
+  for (uint32_t t = 1; t < T && !rc; ++t) {
+    double *Xt = X + (size_t)t * N * d;
+    const double *Xp = X + (size_t)(t - 1) * N * d;
+    oracle_metropolis(A + (size_t)t * N, W + (size_t)(t - 1) * N, N, B, seed, t);
+    oracle_propagate(Xt, Xp, A + (size_t)t * N, N, d, G, Qw, dist, nu, scale, seed, t);
+    if (!hoisted) {
+      oracle_reweight(Xt, N, d, Y + (size_t)t * d, F, V, d, dist, nu, W + (size_t)t * N);
+    } else {
+      /* r_i = y - F x_i  then log-density through the hoisted factor, exponentiated */
+      double *R = (double *)malloc(sizeof(double) * (size_t)N * d);
+      for (uint32_t i = 0; i < N; ++i)
+        for (int a = 0; a < d; ++a) {
+          double s = 0.0;
+          for (int b = 0; b < d; ++b) s += F[a * d + b] * Xt[(size_t)i * d + b];
+          R[(size_t)i * d + a] = Y[(size_t)t * d + a] - s;
+        }
+      rc = oracle_logpdf_hoisted(R, N, d, NULL, V, NULL, d, dist, nu, W + (size_t)t * N);
+      for (uint32_t i = 0; i < N; ++i) W[(size_t)t * N + i] = exp(W[(size_t)t * N + i]);
+      free(R);
+    }
+  }
+  free(Q0); free(Qw);
+  return rc;
+}
+
+ORACLE_API int oracle_num_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

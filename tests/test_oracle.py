@@ -1,0 +1,188 @@
+"""CPU suite, part 1: the oracle (oracle/cusmc_oracle.c) against the reference's own known
+answers, the Random123 known-answer vectors, the committed golden fixtures and scipy.
+No GPU, no libcusmc_hip compute."""
+import numpy as np
+import pytest
+
+from conftest import DIMS, RESAMPLE_CASES, spd
+
+
+# --- the three values the reference publishes -----------------------------------------------
+
+def test_known_answer_mvnpdf(oracle):
+    # CuSMC/CuSMC.tex:95-105, man/MVNPDF.Rd:22-27: MVNPDF(c(0,0), c(0,0), diag(2)) = 0.1591549
+    v = oracle.mvn_pdf([0, 0], [0, 0], np.eye(2), np.eye(2))
+    assert abs(v - 0.1591549) < 5e-8
+    assert abs(v - 1 / (2 * np.pi)) < 1e-16
+
+
+def test_known_answer_mvtpdf(oracle):
+    # CuSMC/CuSMC.tex:131-142: MVTPDF(c(0,0,0), c(0,0,0), diag(3), 3.0) = 0.07799708
+    v = oracle.mvt_pdf([0, 0, 0], [0, 0, 0], np.eye(3), 3.0, np.eye(3))
+    assert abs(v - 0.07799708) < 5e-9
+    assert abs(v - 0.0779970835340203) < 1e-15
+
+
+def test_known_answer_metropolis_zero_weights(oracle):
+    # man/metropolis_hastings.Rd:22-27: w = c(0,0), N = 2, B = 10 -> c(0, 1) (0/0 never accepts)
+    for seed in (0, 1, 12345):
+        assert oracle.metropolis(np.zeros(2), 10, seed).tolist() == [0, 1]
+
+
+# --- RNG contract ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("ctr,key,expect", [
+    ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+])
+def test_philox_known_answers(oracle, ctr, key, expect):
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert oracle.philox4x32_10(ctr, key).tolist() == expect
+
+
+# --- dense LU (what Eigen's determinant()/inverse() do) ------------------------------------------
+
+@pytest.mark.parametrize("d", [1, 2, 5, 17, 64])
+def test_lu_det_inverse(oracle, d):
+    rng = np.random.default_rng(d)
+    S = rng.standard_normal((d, d)) + d * np.eye(d)
+    assert np.isclose(oracle.det(S), np.linalg.det(S), rtol=1e-10)
+    assert np.allclose(oracle.inverse(S) @ S, np.eye(d), atol=1e-10)
+
+
+# --- densities against the fixtures (scipy) ------------------------------------------------------
+
+@pytest.mark.parametrize("d", DIMS)
+@pytest.mark.parametrize("dist", ["mvn", "mvt"])
+def test_pdf_matches_golden(oracle, golden, d, dist):
+    g = lambda k: golden["pdf_d%d_%s" % (d, k)]
+    nu = float(g("nu"))
+    p = oracle.pdf_batch(g("X"), g("mu"), g("sigma"), g("F"), dist, nu)
+    assert np.array_equal(p, g(dist + "_pdf_oracle"))  # the restatement itself has not drifted
+    assert np.allclose(np.log(p), g(dist + "_logpdf_scipy"), rtol=1e-9, atol=1e-9)
+    w = oracle.reweight(g("X"), g("y"), g("F"), g("sigma"), dist, nu)
+    assert np.array_equal(w, g(dist + "_reweight_oracle"))
+    assert np.allclose(np.log(w), g(dist + "_reweight_scipy"), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("d", DIMS)
+@pytest.mark.parametrize("dist", ["mvn", "mvt"])
+def test_hoisted_form_equals_faithful_form(oracle, golden, d, dist):
+    g = lambda k: golden["pdf_d%d_%s" % (d, k)]
+    nu = float(g("nu"))
+    lp = oracle.logpdf_hoisted(g("X"), g("mu"), g("sigma"), g("F"), dist, nu)
+    assert np.allclose(lp, g(dist + "_logpdf_scipy"), rtol=1e-10, atol=1e-10)
+
+
+def test_norms(oracle):
+    rng = np.random.default_rng(3)
+    S = spd(rng, 6)
+    assert np.isclose(oracle.mvn_norm(S), (2 * np.pi) ** -3 * np.linalg.det(S) ** -0.5, rtol=1e-12)
+    from scipy.special import gammaln
+    nu = 2.5
+    ln = gammaln((nu + 6) / 2) - gammaln(nu / 2) - 3 * np.log(np.pi * nu) - 0.5 * np.log(np.linalg.det(S))
+    assert np.isclose(np.log(oracle.mvt_norm(S, nu)), ln, rtol=1e-12)
+
+
+def test_pdf_one_arg_overload_ignores_mu(oracle):
+    # pdf(y) uses y itself in the quadratic form (src/statistics.cc.cpp:171-180)
+    S = spd(np.random.default_rng(5), 4)
+    y = np.array([0.3, -1.0, 0.2, 0.9])
+    assert oracle.mvn_pdf(y, np.ones(4), S, None) == oracle.mvn_pdf(y, np.zeros(4), S, np.eye(4))
+
+
+def test_not_spd_is_reported(oracle):
+    with pytest.raises(ValueError):
+        oracle.logpdf_hoisted(np.zeros((1, 2)), None, np.array([[1.0, 2.0], [2.0, 1.0]]))
+
+
+# --- resampler -----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", RESAMPLE_CASES)
+@pytest.mark.parametrize("B", [1, 10, 37])
+def test_resampler_matches_golden(oracle, golden, name, B):
+    w = golden["resample_%s_w" % name]
+    a = oracle.metropolis(w, B, seed=20240 + B, step=1)
+    assert a.dtype == np.uint32 and a.shape == w.shape
+    assert np.array_equal(a, golden["resample_%s_B%d" % (name, B)])
+    assert a.max() < w.shape[0]
+
+
+def test_resampler_semantics(oracle):
+    # pure-Python restatement of src/samplers.cpp:21-35 on the same Philox stream
+    rng = np.random.default_rng(11)
+    w = rng.random(50)
+    N, B, seed, step = 50, 7, 0xDEADBEEFCAFE, 3
+    key = [seed & 0xFFFFFFFF, seed >> 32]
+    expect = []
+    for i in range(N):
+        k = i
+        for n in range(B):
+            r = oracle.philox4x32_10([i, n, step, 1], key)
+            u = float(((int(r[0]) << 32 | int(r[1])) >> 11) * 2.0 ** -53)
+            j = ((int(r[2]) << 32 | int(r[3])) * N) >> 64
+            if u <= w[j] / w[k]:
+                k = j
+        expect.append(k)
+    assert oracle.metropolis(w, B, seed, step).tolist() == expect
+
+
+def test_resampler_targets_weights(oracle):
+    # long chains forget the start: ancestor frequencies follow w (Murray-Lee-Jacob)
+    w = np.array([1.0, 2.0, 3.0, 4.0] * 250)
+    a = oracle.metropolis(w, 200, seed=5)
+    freq = np.bincount(w[a].astype(int), minlength=5)[1:] / a.size
+    assert np.allclose(freq, [0.1, 0.2, 0.3, 0.4], atol=0.05)
+
+
+def test_resampler_zero_and_dominant(oracle):
+    assert np.array_equal(oracle.metropolis(np.zeros(33), 10, 1), np.arange(33))
+    w = np.r_[np.full(99, 1e-300), 1.0]
+    assert np.mean(oracle.metropolis(w, 400, 2) == 99) > 0.95
+
+
+# --- draws ---------------------------------------------------------------------------------------
+
+def test_eigen_sqrt(oracle):
+    S = spd(np.random.default_rng(8), 9)
+    Q = oracle.eigen_sqrt(S)
+    assert np.allclose(Q @ Q.T, S, atol=1e-12)
+
+
+@pytest.mark.parametrize("scale,var", [(1.0, 1.0), (3 ** 0.5, 3.0)])
+def test_mvn_draw_moments(oracle, scale, var):
+    # scale sqrt(3) = the distribution of the reference's CPU transform
+    S = np.array([[2.0, 0.6], [0.6, 1.0]])
+    X, w = oracle.initialize(200000, [1.0, -2.0], oracle.eigen_sqrt(S), scale=scale, seed=4)
+    assert np.allclose(X.mean(0), [1.0, -2.0], atol=0.02)
+    assert np.allclose(np.cov(X.T), var * S, atol=0.03 * var)
+    assert np.allclose(w, 1 / 200000)
+
+
+def test_mvt_draw_componentwise_chi(oracle):
+    # each component gets its OWN sqrt(nu/chi2): marginals are t_nu, var nu/(nu-2)
+    X, _ = oracle.initialize(200000, [0.0, 0.0], np.eye(2), "mvt", 5.0, seed=9)
+    assert np.allclose(np.var(X, axis=0), 5 / 3, atol=0.05)
+    assert abs(np.corrcoef(X.T)[0, 1]) < 0.01
+
+
+def test_propagate_is_gather_plus_draw(oracle):
+    rng = np.random.default_rng(2)
+    Xp = rng.standard_normal((32, 3))
+    a = rng.integers(0, 32, 32).astype(np.uint32)
+    G = rng.standard_normal((3, 3))
+    X = oracle.propagate(Xp, a, G, np.zeros((3, 3)), seed=1, step=4)  # Q = 0: pure G x[a]
+    assert np.allclose(X, Xp[a] @ G.T, atol=1e-14)
+
+
+def test_filter_matches_golden(oracle, golden):
+    I = np.eye(2)
+    for dist, nu in (("mvn", 0.0), ("mvt", 5.0)):
+        X, w, a = oracle.pf_run(golden["pf_y"], 64, np.zeros(2), I, I, I, 0.5 * I, 0.1 * I, dist, nu,
+                                B=10, seed=99)
+        assert np.array_equal(a, golden["pf_%s_a" % dist])
+        assert np.allclose(X, golden["pf_%s_X" % dist], rtol=0, atol=1e-12)
+        assert np.allclose(w, golden["pf_%s_w" % dist], rtol=1e-10)
+        assert np.all(a[0] == 0) and np.allclose(w[0], 1 / 64)

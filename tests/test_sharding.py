@@ -1,0 +1,77 @@
+"""CPU suite, part 3: the one-process-per-GPU partitioning logic, world_size 2 over gloo.
+The compute is a stand-in (the oracle, allowed in tests/): what is under test is that the
+sharded path produces exactly the single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def test_shard_range_partitions():
+    from cusmc_amd.sharding import shard_counts, shard_range
+    for n in (0, 1, 7, 8, 1000, 10 ** 6 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+            assert max(shard_counts(n, world)) - min(shard_counts(n, world)) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, tmp):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cusmc_amd.sharding import gather_final, shard_range, sharded_map, sharded_resample
+    from oracle import oracle as O
+    rng = np.random.default_rng(123)
+    d = 8
+    A = rng.standard_normal((d, d))
+    sigma = A @ A.T / d + np.eye(d)
+    X = rng.standard_normal((n, d))
+    first, count = shard_range(n, rank, world)
+
+    # leg 1: log-pdf of this rank's particles, no collective
+    lp_local = sharded_map(torch.from_numpy(X[first:first + count]),
+                           lambda x: torch.from_numpy(O.logpdf_hoisted(x.numpy(), None, sigma)))
+    # leg 2: exact sharded resample = all-gather(w) + own index range, global Philox indices
+    w_local = torch.exp(lp_local)
+
+    def resample(w_full, f, c):
+        full = O.metropolis(w_full.numpy(), 10, seed=77, step=2)  # stand-in computes all, keeps own
+        return torch.from_numpy(full[f:f + c].astype(np.int64))
+
+    a_local, w_full = sharded_resample(w_local, n, resample)
+    a_full = gather_final(a_local, n)
+    if rank == 0:
+        np.savez(tmp, lp=w_full.numpy(), a=a_full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [64, 101])
+def test_two_rank_sharded_path_equals_single_process(tmp_path, n, oracle):
+    tmp = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(2, _free_port(), n, tmp), nprocs=2, join=True)
+    got = np.load(tmp)
+    rng = np.random.default_rng(123)
+    d = 8
+    A = rng.standard_normal((d, d))
+    sigma = A @ A.T / d + np.eye(d)
+    X = rng.standard_normal((n, d))
+    w = np.exp(oracle.logpdf_hoisted(X, None, sigma))
+    assert np.array_equal(got["lp"], w)                      # ragged all-gather is exact
+    assert np.array_equal(got["a"], oracle.metropolis(w, 10, seed=77, step=2))
