@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X.
+
+A "step" is one pass of the hot path over one device-resident synthetic batch: the fp64 MVN
+log-density of N = 1e6 particles of dimension d = 64 per GPU (BASELINE.json `metric`:
+"MVN log-pdf evals/sec (1e6 particles, d=64) + MH steps/sec; 1/2/4/8 GPUs").  Particles shard
+embarrassingly: one process per GPU, every rank owns its own 1e6 particles, no collective in the
+data path (weak scaling).  The Metropolis-resampler rate (BASELINE configs[1]:
+1e5 chains, weights = d=32 MVN densities, 1e3 iterations) is measured after the timed region and
+reported as `mh_steps_per_s`.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract: the task statement; roofline terms: DESIGN.md).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_PER_GPU = 1_000_000
+D = 64
+ALGO_BYTES_PER_EVAL = 8 * D + 8  # read the particle once, write one log-density
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MH_N, MH_B, MH_D = 100_000, 1000, 32
+
+
+def make_sigma(d, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((d, d))
+    return A @ A.T / d + np.eye(d)
+
+
+def pmc_child(n, d, launches):
+    """Runs under rocprofv3 --pmc: a few launches of the headline kernel, nothing else."""
+    import numpy as np
+    import torch
+    import cusmc_amd
+    torch.cuda.set_device(0)
+    X = torch.randn(n, d, dtype=torch.float64, device="cuda")
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    D_ = cusmc_amd.MultiVariateNormalDistribution(np.zeros(d), make_sigma(d, 1))
+    D_.ctx.use_torch_stream()
+    for _ in range(launches):
+        D_.pdf_dev(X, out)
+    torch.cuda.synchronize()
+    D_.close()
+
+
+def collect_hbm_traffic(n, d, kernel_substr="logpdf_mfma"):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, collected as
+    MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
+    (4 TCC slots; 3 + 2 do not fit), counter unit KiB, and the gfx950 correction: FETCH_SIZE
+    reports exactly half the bytes of a wide coalesced streaming read (16 B/lane), so it is
+    doubled; WRITE_SIZE is exact.  Runs rocprofv3 on a child copy of this script, BEFORE this
+    process touches the GPU.  Returns None if rocprofv3 is unavailable."""
+    import csv
+    import glob
+    rocprof = "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    total = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+                env = dict(os.environ, TMPDIR="/tmp", CUSMC_PMC_CHILD="%d,%d,%d" % (n, d, 3))
+                cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp,
+                       "--", sys.executable, os.path.abspath(__file__)]
+                subprocess.run(cmd, cwd="/tmp", env=env, check=True, capture_output=True, timeout=300)
+                vals = []
+                for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                    with open(path) as f:
+                        for row in csv.DictReader(f):
+                            if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                                vals.append(float(row["Counter_Value"]))
+                if not vals:
+                    return None
+                total[counter] = sum(vals) / len(vals) * 1024.0
+        return {"fetch_bytes": 2.0 * total["FETCH_SIZE"], "write_bytes": total["WRITE_SIZE"],
+                "hbm_bytes": 2.0 * total["FETCH_SIZE"] + total["WRITE_SIZE"]}
+    except Exception as e:  # profiler missing / refused: report null, never a guess
+        sys.stderr.write("bench: PMC traffic pass unavailable (%s)\n" % e)
+        return None
+
+
+def cpu_baseline(d, budget_s=12.0):
+    """The reference's CPU cost structure on this host's cores: per particle a fresh
+    distribution, an LU determinant and an LU inverse of Sigma, then the dense quadratic form
+    (src/statistics.cc.cpp:171-196 as called from src/mcmc.cpp:193-215) -- the oracle's
+    reference-faithful mode, OpenMP over particles.  Bounded sample, sized from a calibration."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(2)
+    sigma, mu = make_sigma(d, 1), np.zeros(d)
+    F = np.eye(d)
+    cal = rng.standard_normal((512, d))
+    O.pdf_batch(cal[:64], mu, sigma, F)  # warm (thread pool, page faults)
+    t0 = time.perf_counter()
+    O.pdf_batch(cal, mu, sigma, F)
+    rate = 512 / (time.perf_counter() - t0)
+    n = int(min(N_PER_GPU, max(2048, rate * budget_s)))
+    X = rng.standard_normal((n, d))
+    t0 = time.perf_counter()
+    O.pdf_batch(X, mu, sigma, F)
+    dt = time.perf_counter() - t0
+    # second line: the same cores with Sigma factored ONCE (algorithmic gain vs hardware gain)
+    Xh = rng.standard_normal((min(N_PER_GPU, 400_000), d))
+    O.logpdf_hoisted(Xh[:1000], mu, sigma)
+    t1 = time.perf_counter()
+    O.logpdf_hoisted(Xh, mu, sigma)
+    dth = time.perf_counter() - t1
+    return {"value": n / dt, "unit": "evals/s", "cores": O.num_threads(), "kind": "port",
+            "sample": "%d of the %d particles (d=%d), reference-faithful per-particle LU det+inverse, "
+                      "%.1f s" % (n, N_PER_GPU, d, dt),
+            "hoisted_factor_value": Xh.shape[0] / dth}
+
+
+def main():
+    if os.environ.get("CUSMC_PMC_CHILD"):
+        n, d, launches = (int(v) for v in os.environ["CUSMC_PMC_CHILD"].split(","))
+        pmc_child(n, d, launches)
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC traffic passes")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    traffic = None
+    if world == 1 and not args.no_pmc:
+        traffic = collect_hbm_traffic(N_PER_GPU, D)  # child processes; this one has not touched the GPU yet
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import cusmc_amd
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # synthetic batch, resident in HBM before the timed region; every rank owns its own particles
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    X = torch.randn(N_PER_GPU, D, dtype=torch.float64, device="cuda", generator=g)
+    out = torch.empty(N_PER_GPU, dtype=torch.float64, device="cuda")
+    sigma, mu = make_sigma(D, 1), np.zeros(D)
+    mvn = cusmc_amd.MultiVariateNormalDistribution(mu, sigma)
+    mvn.ctx.use_torch_stream()  # launches go on torch's current stream, so torch events see them
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mvn.pdf_dev(X, out)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        mvn.pdf_dev(X, out)
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+
+    # spot parity inside the bench: a 2048-row sample against the oracle (rank 0)
+    parity = None
+    if rank == 0:
+        from oracle import oracle as O
+        idx = torch.arange(0, N_PER_GPU, N_PER_GPU // 2048, device="cuda")[:2048]
+        want = O.logpdf_hoisted(X[idx].cpu().numpy(), mu, sigma)
+        parity = float(np.max(np.abs(out[idx].cpu().numpy() - want) / np.abs(want)))
+
+    # Metropolis resampler rate, BASELINE configs[1] shape (outside the timed region)
+    mh = None
+    if rank == 0:
+        sig32 = make_sigma(MH_D, 2)
+        d32 = cusmc_amd.MultiVariateNormalDistribution(np.zeros(MH_D), sig32)
+        Xw = torch.randn(MH_N, MH_D, dtype=torch.float64, device="cuda", generator=g) @ \
+            torch.from_numpy(np.linalg.cholesky(sig32).T).cuda()
+        w = torch.empty(MH_N, dtype=torch.float64, device="cuda")
+        d32.pdf_dev(Xw.contiguous(), w, log=False)
+        a = torch.empty(MH_N, dtype=torch.int32, device="cuda")
+        ctx = mvn.ctx
+        cusmc_amd.Sampler.metropolis_hastings_dev(w, a, B=MH_B, t=1, seed=1, ctx=ctx)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for r in range(reps):
+            cusmc_amd.Sampler.metropolis_hastings_dev(w, a, B=MH_B, t=2 + r, seed=1, ctx=ctx)
+        e1.record()
+        torch.cuda.synchronize()
+        mh_ms = e0.elapsed_time(e1) / reps
+        mh = {"steps_per_s": MH_N * MH_B / (mh_ms * 1e-3), "ms_per_resample": mh_ms,
+              "workload": "metropolis_hastings N=%d chains, B=%d iters, weights = d=%d MVN densities"
+                          % (MH_N, MH_B, MH_D)}
+        d32.close()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(D)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        evals = world * N_PER_GPU * args.steps
+        achieved = N_PER_GPU * ALGO_BYTES_PER_EVAL / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "MVN log-pdf evals/sec (1e6 particles, d=64)",
+            "value": evals / wall_max,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "mvn_logpdf fp64: N=%d particles per GPU x d=%d, Sigma = AA^T/d + I "
+                                   "(seed 1), device-resident, one launch per step" % (N_PER_GPU, D),
+                       "particles_per_gpu": N_PER_GPU, "d": D, "parallelism": "particle-sharded x%d, "
+                       "no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if traffic is None else traffic["hbm_bytes"],
+                         "algorithmic_bytes_per_launch": N_PER_GPU * ALGO_BYTES_PER_EVAL,
+                         "kernel": "logpdf_mfma_kernel<4,true>", "kernel_ms": kernel_ms,
+                         "frac_of_measured_copy_peak": achieved / 6290.0},
+            "cpu_baseline": cpu,
+            "mh_steps_per_s": None if mh is None else mh["steps_per_s"],
+            "mh": mh,
+            "parity_max_rel_err_vs_oracle": parity,
+        }
+        if traffic is not None:
+            line["roofline"]["traffic_detail"] = traffic
+        print(json.dumps(line), flush=True)
+    mvn.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

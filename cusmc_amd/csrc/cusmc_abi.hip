@@ -189,7 +189,9 @@ int run_logpdf(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx, in
   const int d = dist->d;
   if (cusmc::mfma_supported(d, X_dev, ldx)) {
     if (int rc = ensure_frags(dist)) return rc;
-    HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan_tri, (const double *)dist->frags.p,
+    bool has_shift = false;
+    for (double v : dist->plan_shift) has_shift |= (v != 0.0);
+    HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan_tri, has_shift, (const double *)dist->frags.p,
                                       (const double *)dist->shift.p, (const double *)dist->bias.p,
                                       ep, out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;

@@ -1,0 +1,305 @@
+// Batched multivariate Normal / Student-t log-density for d = 16*NB on gfx950, fp64.
+//
+// Replaces the reference's three-launch pdf pipeline (mvn_pdf_kernel_y_minus_Fmu ->
+// mvn_pdf_kernel_Einv_alpha -> mvn_pdf_kernel, src/mvn_dist.cu.cpp:455-668, and the mvt twins,
+// src/mvt_dist.cu.cpp:356-571) and, on the CPU side, the per-particle
+// MultiVariateNormalDistribution::pdf / MultiVariateTStudentDistribution::pdf
+// (src/statistics.cc.cpp:171-196, :295-324) called from reweight_G (src/mcmc.cpp:193-215).
+//
+// Formulation.  Sigma = L L^T is factored ONCE on the host; with W = L^-1 the Mahalanobis
+// form is q = |W (x - m)|^2.  Over a batch that is Z = R W^T, a [N x d] x [d x d] GEMM whose
+// right factor is lower triangular -- so it runs on the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64), skipping the all-zero 16x16 blocks above the diagonal.  Z is never
+// written: each wave squares and row-sums its accumulators and emits 8 bytes per particle.
+//
+// Mapping (one wave = one tile of 16 particles at a time, persistent over tiles):
+//   B operand  lane (p = lane&15, h = lane>>4) holds r[p][k], k = 16*kb + pi(s,h), for k-step s
+//              of k-block kb, where pi(s,h) = 2h + (s&1) + 8(s>>1).  The k order inside a block
+//              is free (it is a summation index) and this one lets each lane fetch its four
+//              values of a block with two 16-byte loads, 64 contiguous bytes per particle per
+//              load instruction: X goes HBM -> VGPR once, coalesced, with no LDS round trip.
+//   A operand  lane (j = lane&15, h) holds M[16*cb + j][16*kb + pi(s,h)]: the factor, packed on
+//              the host in exactly this order (mfma_pack_frags) and staged ONCE per workgroup in
+//              registers (triangular, d <= 64: 80 VGPRs at d = 64) or, for the dense / large
+//              forms, staged once per workgroup in LDS and read one k-step ahead of its use.
+//   C/D        C = M R^T: lane (p, h), register r  ->  output dim 16*cb + h + 4r of PARTICLE p.
+//              A lane only ever holds one particle's outputs, so the row sum of squares is 16
+//              in-lane FMAs plus one 4-lane reduction over h -- not a 16-lane reduction of four
+//              values, which is what the transposed product costs.
+//   Epilogue   lanes 0..15 finish particles 0..15 of the tile and store one 128-byte line.
+//
+// Roofline: 8d + 8 algorithmic bytes per particle; at d = 64 the kernel needs 40
+// MFMAs of 2048 flop per 16 particles.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../launch.h"
+#include "../../../include/cusmc_hip.h"
+
+namespace cusmc {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int pi_k(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
+
+__device__ __forceinline__ double finish(double q, const Epilogue &ep)
+{
+  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p(q * ep.inv_nu)
+                                     : ep.lognorm - 0.5 * q;
+  return ep.out_density ? exp(lp) : lp;
+}
+
+// TRI  = centred form:  z = W (x - shift), W lower triangular, no bias      (pdf(y, F))
+// !TRI = affine form:   z = bias + M x,    M dense, no shift                (reweight_G)
+// SHIFT = false drops the subtraction when the shift vector is all zeros.
+// ABL is for scripts/calib/ablate.hip only (0 in the library): 1 = no global loads inside the tile
+// loop, 2 = no MFMAs, 3 = no cross-lane reduction, 4 = clock stamps.  It exists to attribute time.
+//
+// Instruction budget.  Measured on gfx950 (scripts/calib/calib.hip): while a v_mfma_f64 runs
+// (64.8 cycles) NO other wave of that SIMD issues VALU work -- an MFMA wave plus an integer-VALU
+// wave take the SUM of their times.  Kernel time per SIMD is therefore (MFMA cycles) + (every
+// VALU instruction of every wave), whatever the occupancy, and each tile's 40 MFMAs (2592
+// cycles) leave room for only a few dozen VALU instructions before the kernel stops being
+// HBM-bound.  Hence: tile addresses are scalar (SGPR base + a loop-invariant 32-bit lane offset),
+// accumulators stay in VGPRs (the library is built with -amdgpu-mfma-vgpr-form, so the epilogue
+// needs no v_accvgpr_read), one accumulator per output block, and the epilogue is 16 FMAs, two
+// adds and one compare per tile.
+//
+// Work distribution.  ONE workgroup per CU, as many waves as the register file admits
+// (mfma_threads<NB>()).  Workgroup b owns tiles b, b+G, b+2G, ... (G = grid size) and its waves
+// pull the next one from a counter in LDS.  Static round-robin over waves loses ~10 %: the
+// older of two waves on a SIMD wins issue arbitration, finishes its share early and leaves the
+// younger one to run alone (measured: 78 us vs 87 us wave lifetimes at d = 64).  The counter is
+// workgroup-local, so there is no global state to reset between launches.
+//
+// Factor residency.  WREG (triangular, d <= 64): each lane keeps its 2*NB*(NB+1) factor values in
+// registers for the whole kernel (80 VGPRs at d = 64) -- the tile loop then has no LDS reads at
+// all.  Otherwise the factor is staged once per workgroup in LDS and read one k-step ahead.
+template <int NB>
+__host__ __device__ constexpr int mfma_threads()
+{
+  return NB == 1 ? 1024 : NB == 2 ? 768 : NB <= 4 ? 512 : 256;
+}
+
+template <int NB, bool TRI, bool SHIFT, int ABL = 0>
+__global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
+    const double *__restrict__ X, long N, long ldx, const double *__restrict__ frags,
+    const double *__restrict__ shift, const double *__restrict__ bias, Epilogue ep,
+    double *__restrict__ out, long num_tiles)
+{
+  constexpr int THREADS = mfma_threads<NB>();
+  constexpr int NFRAG = TRI ? 4 * NB * (NB + 1) / 2 : 4 * NB * NB;
+  constexpr bool WREG = TRI && NB <= 4;
+  extern __shared__ double lds[];
+  double *sShift = lds;              // 16*NB
+  double *sBias = sShift + 16 * NB;  // 16*NB
+  int *sNext = reinterpret_cast<int *>(sBias + 16 * NB);  // the workgroup's tile counter (+pad)
+  double *sF = sBias + 16 * NB + 2;  // NFRAG x 64 (only when !WREG)
+
+  if (!WREG) {
+    // Stage the factor: all of a chunk's 16-byte loads are issued before the first LDS write,
+    // so the prologue costs one memory round trip per chunk, not one per element.
+    constexpr int NV = NFRAG * 32;  // 16-byte elements
+    constexpr int CH = 8;
+    const v2d *g = reinterpret_cast<const v2d *>(frags);
+    v2d *l = reinterpret_cast<v2d *>(sF);
+    for (int base = 0; base < NV; base += CH * THREADS) {
+      v2d tmp[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int i = base + c * THREADS + (int)threadIdx.x;
+        if (i < NV) tmp[c] = g[i];
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int i = base + c * THREADS + (int)threadIdx.x;
+        if (i < NV) l[i] = tmp[c];
+      }
+    }
+  }
+  if (threadIdx.x < 16 * NB) {
+    sShift[threadIdx.x] = shift[threadIdx.x];
+    sBias[threadIdx.x] = bias[threadIdx.x];
+  }
+  if (threadIdx.x == 0) *sNext = 0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int p = lane & 15, h = lane >> 4;
+  // tiles of this workgroup: blockIdx.x + k * gridDim.x, k < my_tiles
+  const long G = gridDim.x;
+  const int my_tiles = (int)((num_tiles - 1 - (long)blockIdx.x) / G) + 1;  // grid <= num_tiles
+  const long last = num_tiles - 1;
+  const long tile_bytes = 128 * ldx;  // 16 rows
+  // per-lane byte offset inside a tile; in the last tile rows past N re-read row N-1 (their
+  // stores are masked).  mfma_supported() guarantees 16*ldx*8 < 2^32.
+  const long tail_rows = N - last * 16;  // 1..16
+  const unsigned lane_off = (unsigned)((long)p * ldx + 2 * h) * 8u;
+  const unsigned lane_off_last = (unsigned)((long)(p < tail_rows ? p : tail_rows - 1) * ldx + 2 * h) * 8u;
+
+  // next tile index of this workgroup, wave-uniform (one LDS atomic per wave per tile)
+  auto grab = [&]() -> int {
+    int k = 0;
+    if (lane == 0) k = atomicAdd(sNext, 1);
+    return __builtin_amdgcn_readfirstlane(k);
+  };
+  auto tile_of = [&](int k) -> long { return (long)blockIdx.x + (long)k * G; };
+
+  // loads tile k; past the end it re-reads the workgroup's first tile (an L2 hit, result unused):
+  // a branch around the prefetch would make hipcc's s_waitcnt placement assume the no-prefetch
+  // path and wait for the prefetched loads at the head of every tile.
+  auto load_tile = [&](int k, v2d(&a)[NB][2]) {
+    const long t = tile_of(k < my_tiles ? k : 0);
+    const char *base = reinterpret_cast<const char *>(X) + t * tile_bytes;  // scalar
+    const unsigned off = t == last ? lane_off_last : lane_off;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      a[kb][0] = *reinterpret_cast<const v2d *>(base + off + 128 * kb);
+      a[kb][1] = *reinterpret_cast<const v2d *>(base + off + 128 * kb + 64);
+    }
+  };
+
+  double wreg[WREG ? NFRAG : 1];
+  if (WREG) {
+#pragma unroll
+    for (int f = 0; f < NFRAG; ++f) wreg[f] = frags[f * 64 + lane];
+  }
+  // (!WREG) the factor fragments are loop-invariant LDS reads; left alone, hipcc hoists all of
+  // them out of the tile loop into spilled registers.  An opaque per-tile lane offset keeps them
+  // as in-loop ds_read_b64.
+  int lds_lane = lane;
+
+  auto compute_tile = [&](int k, const v2d(&a_in)[NB][2]) {
+    const long t = tile_of(k);
+    v4d acc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      if (TRI) {
+        acc[cb] = v4d{0.0, 0.0, 0.0, 0.0};
+      } else {  // C rows are output dims h + 4r of block cb
+        const double *b = sBias + 16 * cb + h;
+        acc[cb] = v4d{b[0], b[4], b[8], b[12]};
+      }
+    }
+    int f = 0;
+    if constexpr (WREG) {
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          double a = a_in[kb][s >> 1][s & 1];
+          if (SHIFT) a -= sShift[16 * kb + pi_k(s, h)];
+#pragma unroll
+          for (int cb = kb; cb < NB; ++cb, ++f) {
+            if (ABL == 2)
+              acc[cb][0] += a + wreg[f];  // keeps loads and factor live without the matrix pipe
+            else  // A = factor rows (output dims), B = particles: C[row = out dim][col = particle]
+              acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(wreg[f], a, acc[cb], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      asm volatile("" : "+v"(lds_lane));
+      // the factor fragment of step n+1 is read from LDS before the MFMAs of step n are issued
+      double w_cur[NB], w_nxt[NB];
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) w_cur[cb] = sF[(f + cb) * 64 + lds_lane];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int lo = TRI ? kb : 0;
+          const int cnt = NB - lo;
+          const int kbn = s == 3 ? kb + 1 : kb;  // the next step's k-block
+          const int lon = TRI ? kbn : 0;
+          if (kbn < NB) {
+#pragma unroll
+            for (int cb = lon; cb < NB; ++cb) w_nxt[cb] = sF[(f + cnt + cb - lon) * 64 + lds_lane];
+          }
+          double a = a_in[kb][s >> 1][s & 1];
+          if (TRI && SHIFT) a -= sShift[16 * kb + pi_k(s, h)];
+#pragma unroll
+          for (int cb = lo; cb < NB; ++cb) {
+            if (ABL == 2)
+              acc[cb][0] += a + w_cur[cb];
+            else
+              acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_cur[cb], a, acc[cb], 0, 0, 0);
+          }
+          f += cnt;
+#pragma unroll
+          for (int cb = 0; cb < NB; ++cb) w_cur[cb] = w_nxt[cb];
+        }
+      }
+    }
+    // lane (p, h) holds output dims {h + 4r} of every block for particle p: square-sum in the
+    // lane, then one 4-lane reduction over h (lanes p, p+16, p+32, p+48).
+    double q = 0.0;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q = fma(acc[cb][r], acc[cb][r], q);
+    }
+    if (ABL != 3) {
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+    }
+    // lanes 0..15: particles 0..15 of the tile, one 128-byte line
+    if (lane < (t == last ? (int)tail_rows : 16)) out[t * 16 + lane] = finish(q, ep);
+  };
+
+  // ABL == 4 (diagnostic build only): shader-clock and 100 MHz wall stamps per wave, written past
+  // the end of `out`, never mixed into an output value.
+  unsigned long long stamp_c = 0, stamp_r = 0;
+  if (ABL == 4 || ABL == 5) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
+  int done = 0;
+
+  int k0 = grab();
+  if (k0 < my_tiles) {
+    if constexpr (NB <= 4) {
+      // Three register sets in rotation: while one tile runs on the matrix cores the loads of
+      // the next TWO are in flight (16 KB per wave).  No register copies: the loop is unrolled
+      // by three with the roles renamed.
+      v2d a0[NB][2], a1[NB][2], a2[NB][2];
+      int k1 = grab();
+      load_tile(k0, a0);
+      load_tile(k1, a1);
+      while (true) {
+        const int k2 = grab();
+        if (ABL != 1 && ABL != 5) load_tile(k2, a2);
+        compute_tile(k0, a0); ++done;
+        if (k1 >= my_tiles) break;
+        k0 = grab();
+        if (ABL != 1 && ABL != 5) load_tile(k0, a0);
+        compute_tile(k1, (ABL == 1 || ABL == 5) ? a0 : a1); ++done;
+        if (k2 >= my_tiles) break;
+        k1 = grab();
+        if (ABL != 1 && ABL != 5) load_tile(k1, a1);
+        compute_tile(k2, (ABL == 1 || ABL == 5) ? a0 : a2); ++done;
+        if (k0 >= my_tiles) break;
+      }
+    } else {  // d >= 96: two sets (three would not fit the register file)
+      v2d a0[NB][2], a1[NB][2];
+      load_tile(k0, a0);
+      while (true) {
+        const int k1 = grab();
+        load_tile(k1, a1);
+        compute_tile(k0, a0);
+        if (k1 >= my_tiles) break;
+        k0 = grab();
+        load_tile(k0, a0);
+        compute_tile(k1, a1);
+        if (k0 >= my_tiles) break;
+      }
+    }
+  }
+  if ((ABL == 4 || ABL == 5) && lane == 0) {
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out + num_tiles * 16);
+    const long wid = (long)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+    dbg[3 * wid] = __builtin_amdgcn_s_memtime() - stamp_c;
+    dbg[3 * wid + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r;
+    dbg[3 * wid + 2] = (unsigned long long)done;
+  }
+}
+
+}  // namespace cusmc

@@ -29,9 +29,12 @@ int mfma_num_frags(int nb, bool tri);
 bool mfma_supported(int d, const void *X, int64_t ldx);
 // Host-side packing of M (d x d row-major) into the fragment order.
 void mfma_pack_frags(const double *M, int d, bool tri, double *frags);
+// tri: centred form (shift, no bias); !tri: affine form (bias, no shift).  has_shift = false
+// promises the shift vector is all zeros.
 hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool tri,
-                              const double *frags, const double *shift, const double *bias,
-                              const Epilogue &ep, double *out, int num_cus, hipStream_t stream);
+                              bool has_shift, const double *frags, const double *shift,
+                              const double *bias, const Epilogue &ep, double *out, int num_cus,
+                              hipStream_t stream);
 
 // --- kernels/logpdf_generic.hip : any d <= 319, lane = particle --------------------------------
 bool generic_supported(int d);

@@ -1,0 +1,116 @@
+// Attribution of logpdf_mfma_kernel<4,true> time on the headline shape (N = 1e6, d = 64):
+// the product kernel vs. variants with the loads / the MFMAs / the epilogue removed, at several
+// grid sizes.  Not product code, not a test.  Build (from repo root):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/calib/ablate scripts/calib/ablate.hip \
+//         cusmc_amd/csrc/build/kernels/logpdf_mfma.o
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <time.h>
+#include <vector>
+
+#include "../../cusmc_amd/csrc/kernels/logpdf_mfma_kernel.h"
+
+using namespace cusmc;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int ABL>
+static float run(const double *X, long N, const double *frags, const double *shift, const double *bias,
+                 double *out, int blocks, int reps)
+{
+  Epilogue ep{-10.0, 0, 0, 0, 0};
+  const size_t lds = (size_t)(32 * 4 + 2) * 8;
+  const long tiles = (N + 15) / 16;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, frags, shift, bias, ep, out, tiles);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, frags, shift, bias, ep, out, tiles);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps * 1e3f;
+}
+
+int main()
+{
+  const long N = 1000000; const int d = 64;
+  std::vector<double> hX((size_t)N * d), M((size_t)d * d, 0.0), frags((size_t)40 * 64), z(64, 0.0);
+  unsigned s = 12345;
+  for (auto &v : hX) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) - (1 << 23)) * (1.0 / (1 << 22)); }
+  for (int i = 0; i < d; ++i) for (int j = 0; j <= i; ++j) { s = s * 1664525u + 1013904223u; M[i * d + j] = (i == j) + 0.1 * ((int)(s >> 8) - (1 << 23)) * (1.0 / (1 << 23)); }
+  mfma_pack_frags(M.data(), d, true, frags.data());
+  double *X, *F, *sh, *bi, *out;
+  CK(hipMalloc(&X, hX.size() * 8)); CK(hipMalloc(&F, frags.size() * 8)); CK(hipMalloc(&sh, 512)); CK(hipMalloc(&bi, 512)); CK(hipMalloc(&out, N * 8 + 16 * 4096 * 8));
+  CK(hipMemcpy(X, hX.data(), hX.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(F, frags.data(), frags.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(sh, z.data(), 512, hipMemcpyHostToDevice)); CK(hipMemcpy(bi, z.data(), 512, hipMemcpyHostToDevice));
+  {  // sustained vs isolated launches of the product variant at 2 blocks/CU
+    Epilogue ep{-10.0, 0, 0, 0, 0};
+    const size_t lds = (size_t)(32 * 4 + 2) * 8;
+    const long tiles = (N + 15) / 16;
+    int occ = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, logpdf_mfma_kernel<4, true, false, 0>, 512, lds);
+    printf("occupancy API (512-thread blocks): %d blocks/CU\n", occ);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int blocks : {256}) {
+      for (int reps : {1, 20, 200, 1000}) {
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < reps; ++i)
+          hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("blocks %d, %4d back-to-back launches: %.1f us each\n", blocks, reps, ms / reps * 1e3);
+      }
+      float tot = 0;
+      for (int i = 0; i < 20; ++i) {
+        (void)hipDeviceSynchronize();
+        struct timespec ts = {0, 3000000}; nanosleep(&ts, nullptr);
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); tot += ms;
+      }
+      printf("blocks %d, isolated launches (3 ms idle between): %.1f us each\n", blocks, tot / 20 * 1e3);
+    }
+  }
+  for (int mode = 0; mode < 2; ++mode) {  // in-kernel clock: full kernel, then the no-loads variant
+    Epilogue ep{-10.0, 0, 0, 0, 0};
+    const size_t lds = (size_t)(32 * 4 + 2) * 8;
+    const long tiles = (N + 15) / 16;
+    for (int i = 0; i < 300; ++i)
+      if (mode == 0) hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 4>), dim3(256), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+      else hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 5>), dim3(256), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(3 * 2048);
+    CK(hipMemcpy(st.data(), out + tiles * 16, st.size() * 8, hipMemcpyDeviceToHost));
+    double csum = 0, rsum = 0, rmax = 0, rmin = 1e30;
+    for (int w = 0; w < 2048; ++w) { csum += st[3 * w]; rsum += st[3 * w + 1]; rmax = rmax > st[3*w+1] ? rmax : st[3*w+1]; rmin = rmin < st[3*w+1] ? rmin : st[3*w+1]; }
+    {
+      double byx[8] = {0}, lo = 0, hi = 0; long tlo = 0, thi = 0;
+      for (int w = 0; w < 2048; ++w) {
+        double r = st[3 * w + 1] / 100.0; int blk = w / 8;
+        byx[blk % 8] += r / 256;
+        if ((w % 8) < 4) { lo += r / 1024; tlo += st[3 * w + 2]; } else { hi += r / 1024; thi += st[3 * w + 2]; }
+      }
+      printf("lifetime by block%%8 (XCD group):"); for (int i = 0; i < 8; ++i) printf(" %.1f", byx[i]); printf("\n");
+      printf("waves 0-3: mean %.1f us, %.1f tiles each; waves 4-7: mean %.1f us, %.1f tiles each\n", lo, tlo / 1024.0, hi, thi / 1024.0);
+      int hist[12] = {0};
+      for (int w = 0; w < 2048; ++w) { int b = (int)((st[3 * w + 1] / 100.0 - 70) / 2); if (b < 0) b = 0; if (b > 11) b = 11; ++hist[b]; }
+      printf("lifetime histogram 70..94us step 2:"); for (int i = 0; i < 12; ++i) printf(" %d", hist[i]); printf("\n");
+    }
+    printf("[%s] in-kernel clock (300 launches)", mode ? "no-loads" : "full"); printf(": %.2f GHz; wave lifetime %.1f us mean, %.1f min, %.1f max\n",
+           csum / rsum * 0.1, rsum / 2048 / 100.0, rmin / 100.0, rmax / 100.0);
+  }
+  printf("blocks/CU |  full  | no-loads | no-mfma | no-epilogue-reduce   (us per launch, N=1e6 d=64)\n");
+  for (int per : {1}) {
+    const int blocks = 256 * per;
+    printf("   %d      | %6.1f | %6.1f   | %6.1f  | %6.1f\n", per, run<0>(X, N, F, sh, bi, out, blocks, 20),
+           run<1>(X, N, F, sh, bi, out, blocks, 20), run<2>(X, N, F, sh, bi, out, blocks, 20),
+           run<3>(X, N, F, sh, bi, out, blocks, 20));
+  }
+  return 0;
+}
