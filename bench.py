@@ -132,8 +132,8 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC traffic passes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
@@ -252,7 +252,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic["hbm_bytes"],
                          "algorithmic_bytes_per_launch": N_PER_GPU * ALGO_BYTES_PER_EVAL,
-                         "kernel": "logpdf_mfma_kernel<4,true>", "kernel_ms": kernel_ms,
+                         "kernel": "cusmc::logpdf_mfma_kernel<4, true, false, 0>", "kernel_ms": kernel_ms,
                          "frac_of_measured_copy_peak": achieved / 6290.0},
             "cpu_baseline": cpu,
             "mh_steps_per_s": None if mh is None else mh["steps_per_s"],

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Condenses a scripts/profile.sh output directory into a short markdown summary
+(kernel names are truncated: torch's generator kernels have 4 KB names)."""
+import csv
+import glob
+import sys
+
+
+def short(n):
+    return n if len(n) < 90 else n[:87] + "..."
+
+
+def main(d):
+    print("# rocprofv3 summary (%s)\n" % d.rstrip("/").split("/")[-1])
+    for f in glob.glob(d + "/kt/**/*kernel_stats.csv", recursive=True):
+        print("## --kernel-trace --stats (python3 bench.py --no-pmc --no-cpu: default steps/warmup)\n")
+        print("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
+        for r in csv.DictReader(open(f)):
+            if float(r["Percentage"]) < 0.05:
+                continue
+            print("| %s | %s | %.1f | %.1f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                           float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for f in glob.glob(d + "/%s/**/*counter_collection.csv" % counter.split("_")[0].lower(), recursive=True):
+            vals = {}
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == counter and "cusmc::" in r["Kernel_Name"]:
+                    vals.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+            print("\n## --pmc %s (KiB per dispatch, raw counter)\n" % counter)
+            for k, v in vals.items():
+                print("- `%s`: mean %.1f KiB over %d dispatches = %.1f MB" % (k, sum(v) / len(v), len(v), sum(v) / len(v) * 1024 / 1e6))
+    print("\nFETCH_SIZE on gfx950 reports half the bytes of a wide (16 B/lane) streaming read "
+          "(MI355X_MICROARCH.md, HBM): double it before comparing with the algorithmic 512 MB; WRITE_SIZE is exact.")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

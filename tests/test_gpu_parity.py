@@ -348,3 +348,16 @@ def test_filter_tracks_a_linear_gaussian_state(cs):
     w = out["weights"][-1]
     est = (out["posterior_x"][-1] * w[:, None]).sum(0) / w.sum()
     assert np.allclose(est, m, atol=0.05)
+
+
+def test_cpp_host_mirror(cs):
+    """cusmc_amd/host/cusmc_host.hpp -- the C++ mirror of the reference's classes -- through its
+    own driver (tests/cpp/host_mirror_test.cpp, built by __graft_entry__.build())."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
