@@ -86,6 +86,7 @@ struct cusmc_dist {
   bool plan_tri = true;
   std::vector<double> plan_F, plan_shift, plan_bias;
   bool frags_valid = false, M_valid = false;
+  int frags_kind = 0;  // which kernel family the device fragments are packed for (1 tile, 2 wide)
   std::vector<double> hostM;
 };
 
@@ -156,17 +157,22 @@ int install_plan(cusmc_dist *dist, int plan, bool tri, const std::vector<double>
   return CUSMC_OK;
 }
 
-int ensure_frags(cusmc_dist *dist)
+int ensure_frags(cusmc_dist *dist, int kind)
 {
-  if (dist->frags_valid) return CUSMC_OK;
+  if (dist->frags_valid && dist->frags_kind == kind) return CUSMC_OK;
   const int d = dist->d, nb = d / 16;
-  const size_t n = (size_t)cusmc::mfma_num_frags(nb, dist->plan_tri) * 64;
+  const size_t n = kind == 2 ? cusmc::mfma_wide_frag_doubles(nb, dist->plan_tri)
+                             : (size_t)cusmc::mfma_num_frags(nb, dist->plan_tri) * 64;
   std::vector<double> frags(n);
-  cusmc::mfma_pack_frags(dist->hostM.data(), d, dist->plan_tri, frags.data());
+  if (kind == 2)
+    cusmc::mfma_wide_pack_frags(dist->hostM.data(), d, dist->plan_tri, frags.data());
+  else
+    cusmc::mfma_pack_frags(dist->hostM.data(), d, dist->plan_tri, frags.data());
   if (int rc = dist->frags.reserve(n * 8)) return rc;
   HIP_TRY(hipMemcpyAsync(dist->frags.p, frags.data(), n * 8, hipMemcpyHostToDevice, dist->ctx->stream));
   HIP_TRY(hipStreamSynchronize(dist->ctx->stream));
   dist->frags_valid = true;
+  dist->frags_kind = kind;
   return CUSMC_OK;
 }
 
@@ -187,10 +193,17 @@ int run_logpdf(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx, in
   cusmc_ctx *ctx = dist->ctx;
   const Epilogue ep = make_epilogue(dist, flags);
   const int d = dist->d;
+  bool has_shift = false;
+  for (double v : dist->plan_shift) has_shift |= (v != 0.0);
+  if (cusmc::mfma_wide_supported(d, X_dev, ldx)) {
+    if (int rc = ensure_frags(dist, 2)) return rc;
+    HIP_TRY(cusmc::launch_logpdf_mfma_wide(X_dev, N, ldx, d, dist->plan_tri, has_shift,
+                                           (const double *)dist->frags.p, (const double *)dist->shift.p,
+                                           (const double *)dist->bias.p, ep, out_dev, ctx->num_cus, ctx->stream));
+    return CUSMC_OK;
+  }
   if (cusmc::mfma_supported(d, X_dev, ldx)) {
-    if (int rc = ensure_frags(dist)) return rc;
-    bool has_shift = false;
-    for (double v : dist->plan_shift) has_shift |= (v != 0.0);
+    if (int rc = ensure_frags(dist, 1)) return rc;
     HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan_tri, has_shift, (const double *)dist->frags.p,
                                       (const double *)dist->shift.p, (const double *)dist->bias.p,
                                       ep, out_dev, ctx->num_cus, ctx->stream));

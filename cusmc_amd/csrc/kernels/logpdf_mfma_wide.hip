@@ -1,0 +1,401 @@
+// Batched MVN / Student-t log-density for large d = 16*NB, NB in {8, 12, 16} (d = 128, 192, 256):
+// the regime where (X - mu) L^-T is a genuine dense GEMM and the kernel is bound by the f64 matrix
+// cores, not by HBM (d = 256: 2056 B and ~70 kflop per particle = 34 flop/B against a machine
+// balance of 9.8).  Same contract and same reference functions as kernels/logpdf_mfma_kernel.h:
+//     z = bias + M (x - shift),  q = z.z,  out = epilogue(q)
+//
+// Why a second kernel.  At d = 256 the block-triangular factor is 278 KB: it fits neither the
+// register file nor LDS, and one wave cannot hold 16 output blocks of accumulators for several
+// particle tiles.  So the OUTPUT dimension is split over the waves of a workgroup:
+//   * one workgroup per CU; it walks groups of GP particles (32, or 64 at d = 128);
+//   * wave w owns the PAIR of output blocks (q, NB-1-q), q = w % (NB/2), for two particle tiles
+//     (the tiles 2r, 2r+1 of the group, r = w / (NB/2)).  In the triangular form block cb needs
+//     k-blocks 0..cb, so every pair costs (q+1) + (NB-q) = NB+1 block-products: all waves carry
+//     exactly the same number of MFMAs (136 / 8 = 17 at d = 256);
+//   * accumulators are 2 tiles x 2 blocks x 8 = 32 VGPRs, which leaves the register file free
+//     for software pipelining.  That matters more than anything else here: an f64 MFMA blocks
+//     VALU issue on its SIMD and a wave is in-order, so every operand must already be in a
+//     register when its MFMA is due.  Earlier versions of this kernel ran at
+//     256 VGPRs and hipcc sank every prefetch next to its use: 35-40 % of the time both waves of
+//     a SIMD sat in s_waitcnt (scripts/calib/ablate_wide.cpp);
+//   * particle rows: staged ONCE per group in LDS in MFMA operand order
+//     ([k-block][half][tile][lane][2]: one conflict-free ds_read_b128 per two operands), double
+//     buffered, and filled by a DEDICATED LOADER WAVE (the last wave of the workgroup; LDS-DMA,
+//     so no VGPR or VALU traffic beside the compute waves of its SIMD) while the
+//     compute waves work on the other buffer -- a whole group (~8 us) of prefetch distance.  The
+//     HBM stream needs its own wave because vmcnt retires in order: any wave that has an HBM
+//     miss in flight makes its later, L2-resident fragment loads wait behind it (measured: the
+//     first fragment wait of every group stalled for the full HBM latency);
+//   * factor fragments: streamed from L2 with buffer loads (SGPR descriptor + lane offset; flat
+//     loads make hipcc materialise dozens of 64-bit pointers), each used by two MFMAs, fetched a
+//     whole k-block ahead into the idle one of two register sets (k loop unrolled by two: no
+//     register copies);
+//   * C has particles on columns: a lane's accumulators belong to one particle, so the partial
+//     sum of squares is in-lane FMAs + one 4-lane reduction; the waves' partials meet in LDS
+//     once per group (the only barrier) and are added in a fixed order.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "../launch.h"
+#include "../../../include/cusmc_hip.h"
+
+namespace cusmc {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int wide_pairs(int nb) { return nb / 2; }
+__host__ __device__ constexpr int wide_row_halves(int nb) { return nb == 8 ? 2 : 1; }
+__host__ __device__ constexpr int wide_waves(int nb) { return wide_pairs(nb) * wide_row_halves(nb); }
+__host__ __device__ constexpr int wide_gp(int nb) { return 32 * wide_row_halves(nb); }  // particles per group
+__host__ __device__ constexpr int wide_pi(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
+
+bool mfma_wide_supported(int d, const void *X, int64_t ldx)
+{
+  if (d != 128 && d != 192 && d != 256) return false;
+  // a group of <= 64 rows is addressed through one 32-bit buffer descriptor
+  return ((uintptr_t)X % 16 == 0) && (ldx % 2 == 0) && (ldx < (1L << 21));
+}
+
+// fragments in the stream of pair q (kernel loop order: kb, s, live members)
+static long wide_stream_frags(int nb, bool tri, int q)
+{
+  if (!tri) return 8L * nb;                      // both blocks at every k-block
+  return 4L * (2 * (q + 1) + (nb - 1 - 2 * q));  // both up to kb = q, then the high block alone
+}
+
+static size_t wide_lds_bytes(int nb)
+{
+  const int tiles = wide_gp(nb) / 16;
+  return (size_t)(2 * nb * 4 * tiles * 64 + 2 * wide_waves(nb) * 32 + 32 * nb) * sizeof(double);
+}
+
+size_t mfma_wide_frag_doubles(int nb, bool tri)
+{
+  size_t n = 0;
+  for (int q = 0; q < wide_pairs(nb); ++q) n += (size_t)wide_stream_frags(nb, tri, q) * 64;
+  return n + 9 * 64;  // zero tail: the kernel prefetches one k-block past a stream's end
+}
+
+// streams back to back; a fragment holds, for lane l = (j, h), M[16*cb + j][16*kb + pi(s,h)]
+void mfma_wide_pack_frags(const double *M, int d, bool tri, double *frags)
+{
+  const int nb = d / 16;
+  const size_t total = mfma_wide_frag_doubles(nb, tri);
+  for (size_t i = total - 9 * 64; i < total; ++i) frags[i] = 0.0;
+  size_t f = 0;
+  for (int q = 0; q < wide_pairs(nb); ++q) {
+    const int lo = q, hi = nb - 1 - q;
+    for (int kb = 0; kb < nb; ++kb)
+      for (int s = 0; s < 4; ++s)
+        for (int m = 0; m < 2; ++m) {
+          const int cb = m ? hi : lo;
+          if (tri && cb < kb) continue;
+          for (int l = 0; l < 64; ++l) {
+            const int j = l & 15, h = l >> 4;
+            frags[f * 64 + l] = M[(size_t)(16 * cb + j) * d + 16 * kb + wide_pi(s, h)];
+          }
+          ++f;
+        }
+  }
+}
+
+static __device__ __forceinline__ double finish_wide(double q, const Epilogue &ep)
+{
+  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p(q * ep.inv_nu)
+                                     : ep.lognorm - 0.5 * q;
+  return ep.out_density ? exp(lp) : lp;
+}
+
+struct WideStreams { int byte_off[8]; };  // start of each pair's fragment stream
+
+// ABL (scripts/calib only; 0 in the library): 1 = fragments not re-fetched, 2 = next group's rows
+// not fetched, 3 = neither.  Attribution of stall time; results are wrong by construction.
+template <int NB, bool TRI, bool SHIFT, int ABL = 0>
+__global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_kernel(
+    const double *__restrict__ X, long N, long ldx, const double *__restrict__ frags,
+    WideStreams streams, long frag_bytes, const double *__restrict__ shift,
+    const double *__restrict__ bias, Epilogue ep, double *__restrict__ out, long num_groups)
+{
+  constexpr int P = wide_pairs(NB);
+  constexpr int WAVES = wide_waves(NB);  // compute waves; wave WAVES is the loader
+  constexpr int THREADS = 64 * (WAVES + 1);
+  constexpr int GP = wide_gp(NB);
+  constexpr int TILES = GP / 16;
+  constexpr int XBUF = NB * 4 * TILES * 64;  // doubles per staging buffer
+  extern __shared__ double lds[];
+  double *sX = lds;                  // [2][NB][2 halves][TILES][64 lanes][2]
+  double *sPartial = sX + 2 * XBUF;  // [2][WAVES][32]
+  double *sShift = sPartial + 2 * WAVES * 32;
+  double *sBias = sShift + 16 * NB;
+
+  for (int i = threadIdx.x; i < 16 * NB; i += THREADS) {
+    sShift[i] = shift[i];
+    sBias[i] = bias[i];
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long G = gridDim.x;
+
+  if (w == WAVES) {
+    // ---------------- loader wave: HBM -> LDS by LDS-DMA, one group ahead ---------------------
+    // It shares a SIMD with two compute waves and anything it pushes through the vector ALU or
+    // the VGPR file holds up their MFMAs (VGPR staging + ds_write cost 25 % of the kernel), so it
+    // moves the rows with `buffer_load_dwordx4 ... lds`: no VGPR data, no VALU.  One instruction
+    // deposits a 1 KB slab = (k-block kb, half h2, tile t): lane (p, h) fetches the 16 bytes
+    // x[16 t + p][16 kb + 8 h2 + 2h .. +1] -- the operands of k-steps 2 h2, 2 h2 + 1 of that lane --
+    // and the DMA puts lane l's chunk at slab + 16 l.  Global side: voffset = (p ldx + 2h) 8
+    // (loop-invariant), soffset = (16 t ldx + 16 kb + 8 h2) 8 (scalar).  The compute waves read
+    // a slab back with one conflict-free ds_read_b128 per lane.
+    const int d_bytes = 128 * NB;
+    const int voff = (int)(((long)(lane & 15) * ldx + 2 * (lane >> 4)) * 8);
+    const int tile_bytes = (int)(16 * ldx * 8);
+    auto stage_group = [&](long g, double *buf) {
+      long rows = N - g * GP;
+      rows = rows < GP ? rows : GP;
+      if (rows <= 0) return;
+      // the descriptor covers exactly the group's valid bytes: rows past N are out of range
+      // (never written or zero: either way only those rows' own, unstored, outputs see them)
+      const long bytes = ((rows - 1) * ldx) * 8 + d_bytes;
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(X + g * GP * ldx), 0, (int)bytes, 0x00020000);
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) {
+            auto *dst = (__attribute__((address_space(3))) void *)(buf + ((kb * 2 + h2) * TILES + t) * 128);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, t * tile_bytes + 128 * kb + 64 * h2, 0, 0);
+          }
+    };
+    stage_group(blockIdx.x, sX);
+    __syncthreads();
+    int parity = 0;
+    for (long g = blockIdx.x; g < num_groups; g += G, parity ^= 1) {
+      if (ABL != 2 && ABL != 3) stage_group(g + G, sX + (parity ^ 1) * XBUF);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------- compute waves ---------------------------------------------------------------
+  const int p = lane & 15, h = lane >> 4;
+  const int q = w % P, rhalf = w / P;  // scalar: output pair, row half
+  const int lo = q, hi = NB - 1 - q;
+  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(frags), 0, (int)frag_bytes, 0x00020000);
+  const int wbyte0 = streams.byte_off[q];
+  const int wlane = lane * 8;
+  auto load_w = [&](int fi) -> double {  // fragment fi of this wave's stream
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, wlane, wbyte0 + fi * 512, 0));
+  };
+
+  __syncthreads();  // the first group is staged
+  int parity = 0;
+  for (long g = blockIdx.x; g < num_groups; g += G, parity ^= 1) {
+    // this wave's two tiles of the current buffer: slab (kb, h2, t) holds, per lane, the operands
+    // of k-steps 2 h2 and 2 h2 + 1
+    const v2d *xw = reinterpret_cast<const v2d *>(sX + parity * XBUF) + (rhalf * 2) * 64 + lane;
+
+    v4d acc[2][2];  // [tile][member: 0 = lo block, 1 = hi block]
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      v4d init = v4d{0.0, 0.0, 0.0, 0.0};
+      if (!TRI) {  // C rows are output dims h + 4r of block cb
+        const double *b = sBias + 16 * (m ? hi : lo) + h;
+        init = v4d{b[0], b[4], b[8], b[12]};
+      }
+      acc[0][m] = init;
+      acc[1][m] = init;
+    }
+
+    // Lookahead.  A k-block is only 8 (two live blocks) or 4 (one) MFMAs per wave, 520 / 260
+    // cycles, so operands are requested a whole k-block ahead: wc/wn hold the fragments of the
+    // current / next k-block (L2, ~600+ cycles), xa/xb its particle operands (LDS, ~150).  The
+    // k loop is unrolled by two so that the sets swap roles without copies.
+    double wc[4][2], wn[4][2];
+    v2d xa[2][2], xb[2][2];  // [half][tile]
+    int f = 0;  // fragment cursor in this wave's stream (scalar)
+    auto load_x = [&](int kb, v2d(&x)[2][2]) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const v2d *src = xw + ((kb * 2 + h2) * TILES) * 64;
+        x[h2][0] = src[0];
+        x[h2][1] = src[64];
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wc[s][i] = load_w(s * 2 + i);
+    load_x(0, xa);
+
+    // one k-block with M live members (slot i = member 2 - M + i): prefetch the next k-block's
+    // operands into (wnext, xnext), then 4 k-steps of 2*M MFMAs from (wcur, xcur)
+    auto kblock = [&](auto mtag, int kb, int mn, double(&wcur)[4][2], double(&wnext)[4][2],
+                      v2d(&xcur)[2][2], v2d(&xnext)[2][2]) {
+      constexpr int M = decltype(mtag)::value;
+      constexpr int C0 = 2 - M;
+      f += 4 * M;
+      if (ABL != 1 && ABL != 3) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < M; ++i) wnext[s][i] = load_w(f + s * mn + i);
+      }
+      load_x(kb + 1, xnext);  // one k-block past the end stays inside LDS and is never used
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        double r0 = xcur[s >> 1][0][s & 1], r1 = xcur[s >> 1][1][s & 1];
+        if (TRI && SHIFT) {
+          const double sh = sShift[16 * kb + wide_pi(s, h)];
+          r0 -= sh;
+          r1 -= sh;
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          acc[0][C0 + i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wcur[s][i], r0, acc[0][C0 + i], 0, 0, 0);
+          acc[1][C0 + i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wcur[s][i], r1, acc[1][C0 + i], 0, 0, 0);
+        }
+      }
+    };
+    // a phase = k-blocks [kb_lo, kb_hi) with M live members; `odd` tells which register set is
+    // current on entry, and the phase returns the parity for the next one
+    auto run_phase = [&](auto mtag, int kb_lo, int kb_hi, bool odd) -> bool {
+      constexpr int M = decltype(mtag)::value;
+      int kb = kb_lo;
+      if (odd && kb < kb_hi) {  // re-align: one k-block from the (n) sets
+        kblock(mtag, kb, (kb + 1 < kb_hi) ? M : 1, wn, wc, xb, xa);
+        ++kb;
+        odd = false;
+      }
+#pragma unroll 1
+      for (; kb + 1 < kb_hi; kb += 2) {
+        kblock(mtag, kb, M, wc, wn, xa, xb);
+        kblock(mtag, kb + 1, (kb + 2 < kb_hi) ? M : 1, wn, wc, xb, xa);
+      }
+      if (kb < kb_hi) {
+        kblock(mtag, kb, 1, wc, wn, xa, xb);
+        odd = true;
+      }
+      return odd;
+    };
+    if constexpr (TRI) {
+      const bool odd = run_phase(std::integral_constant<int, 2>{}, 0, lo + 1, false);
+      run_phase(std::integral_constant<int, 1>{}, lo + 1, hi + 1, odd);
+    } else {
+      run_phase(std::integral_constant<int, 2>{}, 0, NB, false);
+    }
+
+    // partial sums of squares over this wave's two output blocks, per particle
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      double qq = 0.0;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qq = fma(acc[t][m][r], acc[t][m][r], qq);
+      qq += __shfl_xor(qq, 16);
+      qq += __shfl_xor(qq, 32);
+      if (h == 0) sPartial[(parity * WAVES + w) * 32 + t * 16 + p] = qq;
+    }
+    __syncthreads();  // partials visible; the loader has completed the other buffer
+    if (q == 0 && lane < 32) {  // fixed summation order -> bitwise reproducible
+      const double *sp = sPartial + (parity * WAVES + rhalf * P) * 32 + lane;
+      double tot = sp[0];
+#pragma unroll
+      for (int k = 1; k < P; ++k) tot += sp[k * 32];
+      const long row = g * GP + rhalf * 32 + lane;
+      if (row < N) out[row] = finish_wide(tot, ep);
+    }
+  }
+}
+
+template <int NB, bool TRI>
+static WideStreams wide_streams()
+{
+  WideStreams st{};
+  long off = 0;
+  for (int q = 0; q < wide_pairs(NB); ++q) {
+    st.byte_off[q] = (int)(off * 8);
+    off += wide_stream_frags(NB, TRI, q) * 64;
+  }
+  return st;
+}
+
+template <int NB, bool TRI, bool SHIFT>
+static hipError_t launch_wide(const double *X, int64_t N, int64_t ldx, const double *frags,
+                              const double *shift, const double *bias, const Epilogue &ep,
+                              double *out, int num_cus, hipStream_t stream)
+{
+  auto kern = logpdf_mfma_wide_kernel<NB, TRI, SHIFT>;
+  const size_t lds_bytes = wide_lds_bytes(NB);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  constexpr int GP = wide_gp(NB);
+  const long num_groups = (N + GP - 1) / GP;
+  long blocks = num_cus;  // one workgroup per CU (two staging buffers fill the LDS)
+  if (blocks > num_groups) blocks = num_groups;
+  const long frag_bytes = (long)mfma_wide_frag_doubles(NB, TRI) * 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * (wide_waves(NB) + 1)), lds_bytes, stream, X, (long)N,
+                     (long)ldx, frags, wide_streams<NB, TRI>(), frag_bytes, shift, bias, ep, out, num_groups);
+  return hipGetLastError();
+}
+
+// calibration entry (scripts/calib/ablate_wide.cpp): d = 256, triangular, no shift, variant abl
+hipError_t launch_wide_ablate(int abl, const double *X, int64_t N, const double *frags, const double *zeros,
+                              double *out, int blocks, hipStream_t stream)
+{
+  Epilogue ep{-10.0, 0, 0, 0, 0};
+  const long num_groups = (N + 31) / 32;
+  const long fb = (long)mfma_wide_frag_doubles(16, true) * 8;
+  const size_t lds = wide_lds_bytes(16);
+#define CUSMC_ABL(a)                                                                                           \
+  case a:                                                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(logpdf_mfma_wide_kernel<16, true, false, a>),     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    hipLaunchKernelGGL((logpdf_mfma_wide_kernel<16, true, false, a>), dim3(blocks), dim3(576), lds, stream, X, \
+                       (long)N, 256L, frags, wide_streams<16, true>(), fb, zeros, zeros, ep, out, num_groups);  \
+    break;
+  switch (abl) { CUSMC_ABL(0) CUSMC_ABL(1) CUSMC_ABL(2) CUSMC_ABL(3) }
+#undef CUSMC_ABL
+  return hipGetLastError();
+}
+
+int wide_occupancy_probe()
+{
+  int n = -1;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(logpdf_mfma_wide_kernel<16, true, false, 0>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes(16));
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, logpdf_mfma_wide_kernel<16, true, false, 0>, 576,
+                                                     wide_lds_bytes(16));
+  return n;
+}
+
+hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+                                   bool has_shift, const double *frags, const double *shift,
+                                   const double *bias, const Epilogue &ep, double *out,
+                                   int num_cus, hipStream_t stream)
+{
+  if (N <= 0) return hipSuccess;
+#define CUSMC_WIDE(nb)                                                                             \
+  case nb:                                                                                         \
+    if (!tri) return launch_wide<nb, false, false>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream); \
+    return has_shift ? launch_wide<nb, true, true>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream)  \
+                     : launch_wide<nb, true, false>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream);
+  switch (d / 16) {
+    CUSMC_WIDE(8)
+    CUSMC_WIDE(12)
+    CUSMC_WIDE(16)
+  }
+#undef CUSMC_WIDE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace cusmc

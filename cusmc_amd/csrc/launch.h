@@ -36,6 +36,15 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
                               const double *bias, const Epilogue &ep, double *out, int num_cus,
                               hipStream_t stream);
 
+// --- kernels/logpdf_mfma_wide.hip : d in {128, 192, 256}, output blocks split over 4 waves ------
+bool mfma_wide_supported(int d, const void *X, int64_t ldx);
+size_t mfma_wide_frag_doubles(int nb, bool tri);
+void mfma_wide_pack_frags(const double *M, int d, bool tri, double *frags);
+hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+                                   bool has_shift, const double *frags, const double *shift,
+                                   const double *bias, const Epilogue &ep, double *out,
+                                   int num_cus, hipStream_t stream);
+
 // --- kernels/logpdf_generic.hip : any d <= 319, lane = particle --------------------------------
 bool generic_supported(int d);
 hipError_t launch_logpdf_generic(const double *X, int64_t N, int64_t ldx, int d, bool tri,

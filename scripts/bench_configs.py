@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Times the per-GPU share of every BASELINE.json config on one MI355X (device-resident inputs,
+HIP events on the launch stream) and prints a markdown table for BASELINE.md section 4.
+Not the judged bench (that is bench.py); these are the parity-test shapes, timed."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import cusmc_amd  # noqa: E402
+
+
+def spd(d, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((d, d))
+    return A @ A.T / d + np.eye(d)
+
+
+def timed(fn, reps, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def main():
+    rows = []
+    ctx = cusmc_amd.api.default_context().use_torch_stream()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    # log-pdf shapes
+    for name, N, d, dist, nu in (("C1 MVNPDF 1e4 x d=8", 10_000, 8, "mvn", 0.0),
+                                 ("headline MVN 1e6 x d=64", 1_000_000, 64, "mvn", 0.0),
+                                 ("C4 MVT(nu=4) 1e6 x d=64", 1_000_000, 64, "mvt", 4.0),
+                                 ("C5 share MVN 5e5 x d=256", 500_000, 256, "mvn", 0.0),
+                                 ("MVN 1e6 x d=128", 1_000_000, 128, "mvn", 0.0),
+                                 ("MVN 2e6 x d=32", 2_000_000, 32, "mvn", 0.0)):
+        X = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+        out = torch.empty(N, dtype=torch.float64, device="cuda")
+        D = (cusmc_amd.MultiVariateNormalDistribution(np.zeros(d), spd(d, 1), ctx=ctx) if dist == "mvn"
+             else cusmc_amd.MultiVariateTStudentDistribution(np.zeros(d), spd(d, 1), nu, ctx=ctx))
+        t = timed(lambda: D.pdf_dev(X, out), 200 if N * d <= 7e7 else 60, 30)
+        nb = d // 16
+        flops = N / 16 * 2 * nb * (nb + 1) * 2048 if d % 16 == 0 else N * (d * d + 4 * d)
+        rows.append((name, "%.3g evals/s" % (N / t), "%.1f us" % (t * 1e6), "%.2f TB/s" % (N * (8 * d + 8) / t / 1e12),
+                     "%.1f TFLOP/s" % (flops / t / 1e12)))
+        D.close()
+        del X, out
+    # resampler shapes
+    for name, N, B in (("C2 MH 1e5 chains x 1e3", 100_000, 1000), ("C3 step MH 1e6 x 10", 1_000_000, 10),
+                       ("C4 share MH 1.25e5 of 1e6 chains x 1e4", 1_000_000, 10_000)):
+        w = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 1e-20
+        count = 125_000 if "share" in name else N
+        a = torch.empty(count, dtype=torch.int32, device="cuda")
+        st = [0]
+
+        def f():
+            st[0] += 1
+            cusmc_amd.Sampler.metropolis_hastings_dev(w, a, B=B, t=st[0], seed=1, first=0, ctx=ctx)
+        t = timed(f, 3 if B >= 1000 else 50, 1)
+        rows.append((name, "%.3g steps/s" % (count * B / t), "%.3f ms" % (t * 1e3), "-", "-"))
+    # filter (host round trip included: that is what run() does)
+    for name, N, d, T in (("C3 run() N=1e6 d=2 T=100", 1_000_000, 2, 100), ("run() N=2e5 d=64 T=10", 200_000, 64, 10)):
+        I = np.eye(d)
+        Y = np.cumsum(0.03 * np.random.default_rng(0).standard_normal((d, T)), axis=1)
+        t0 = time.perf_counter()
+        cusmc_amd.run(N, d, T, Y, np.zeros(d), I, I, I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn", seed=3)
+        t = time.perf_counter() - t0
+        rows.append((name, "%.3g particle-steps/s" % (N * (T - 1) / t), "%.3f s wall" % t, "-", "-"))
+    print("| config | rate | time | algorithmic HBM | MFMA |\n|---|---|---|---|---|")
+    for r in rows:
+        print("| " + " | ".join(r) + " |")
+
+
+if __name__ == "__main__":
+    main()

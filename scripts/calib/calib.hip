@@ -75,6 +75,8 @@ __global__ __launch_bounds__(1024) void rate_kernel(double *out, int iters, int 
   const bool do_valu = (mode == 1) || (mode == 2 && (wave & 4) != 0);
   const bool do_int = (mode == 3 && (wave & 4) != 0) || mode == 5;
   const bool do_lds = (mode == 4 && (wave & 4) != 0) || mode == 6;
+  const bool do_lds_pure = (mode == 7 && (wave & 4) != 0) || mode == 8;
+  const bool do_gld_pure = (mode == 9 && (wave & 4) != 0) || mode == 10;
   __shared__ double sl[1024];
   sl[threadIdx.x] = threadIdx.x;
   __syncthreads();
@@ -88,6 +90,31 @@ __global__ __launch_bounds__(1024) void rate_kernel(double *out, int iters, int 
       }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    return;
+  }
+  if (do_lds_pure) {  // 16 ds_read_b64 per iteration, NO VALU: results only kept alive
+    unsigned addr = (threadIdx.x & 63) * 8;
+    for (int i = 0; i < iters; ++i) {
+      double r0, r1, r2, r3, r4, r5, r6, r7;
+      asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:512\n ds_read_b64 %2, %8 offset:1024\n ds_read_b64 %3, %8 offset:1536\n"
+                   "ds_read_b64 %4, %8 offset:2048\n ds_read_b64 %5, %8 offset:2560\n ds_read_b64 %6, %8 offset:3072\n ds_read_b64 %7, %8 offset:3584\n"
+                   "s_waitcnt lgkmcnt(0)\n"
+                   "ds_read_b64 %0, %8 offset:4096\n ds_read_b64 %1, %8 offset:4608\n ds_read_b64 %2, %8 offset:5120\n ds_read_b64 %3, %8 offset:5632\n"
+                   "ds_read_b64 %4, %8 offset:6144\n ds_read_b64 %5, %8 offset:6656\n ds_read_b64 %6, %8 offset:7168\n ds_read_b64 %7, %8 offset:7680\n"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7) : "v"(addr) : "memory");
+    }
+    return;
+  }
+  if (do_gld_pure) {  // 8 global_load_dwordx2 (L2/L1 hits) per iteration, no VALU
+    const double *gp = out + (threadIdx.x & 63);
+    for (int i = 0; i < iters / 2; ++i) {
+      double r0, r1, r2, r3, r4, r5, r6, r7;
+      asm volatile("global_load_dwordx2 %0, %8, off\n global_load_dwordx2 %1, %8, off offset:512\n global_load_dwordx2 %2, %8, off offset:1024\n global_load_dwordx2 %3, %8, off offset:1536\n"
+                   "global_load_dwordx2 %4, %8, off offset:2048\n global_load_dwordx2 %5, %8, off offset:2560\n global_load_dwordx2 %6, %8, off offset:3072\n global_load_dwordx2 %7, %8, off offset:3584\n"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7) : "v"(gp) : "memory");
+    }
     return;
   }
   if (do_lds) {  // 16 ds_read_b64 per iteration
@@ -197,10 +224,11 @@ int main()
     double flop = (double)g_blocks * 4 * g_iters * 4 * 2048 + (double)g_blocks * 256 * g_iters * 64 * 2;
     printf("mixed (1 MFMA wave + 1 VALU wave per SIMD): %.3f ms, %.1f TFLOP/s total\n", ms, flop / ms / 1e9);
   }
-  for (int m = 3; m <= 6; ++m) {
-    g_blocks = cus; g_threads = (m <= 4) ? 512 : 256; g_mode = m;
+  for (int m = 3; m <= 10; ++m) {
+    g_blocks = cus; g_threads = (m <= 4 || m == 7 || m == 9) ? 512 : 256; g_mode = m;
     float ms = time_launch(launch_rate, 3);
-    const char *nm[] = {"", "", "", "mixed MFMA wave + int-VALU wave per SIMD", "mixed MFMA wave + LDS-read wave per SIMD", "int-VALU alone (1 wave/SIMD)", "LDS-read alone (1 wave/SIMD)"};
+    const char *nm[] = {"", "", "", "mixed MFMA wave + int-VALU wave per SIMD", "mixed MFMA wave + LDS-read wave per SIMD", "int-VALU alone (1 wave/SIMD)", "LDS-read alone (1 wave/SIMD)",
+                        "mixed MFMA wave + PURE ds_read wave (no VALU)", "pure ds_read alone", "mixed MFMA wave + PURE global_load wave (no VALU)", "pure global_load alone"};
     printf("%s: %.3f ms\n", nm[m], ms);
   }
   {  // random operands, clock
