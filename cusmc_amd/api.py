@@ -27,7 +27,7 @@ from . import _lib
 from ._lib import MVN as _MVN, MVT as _MVT, OUT_DENSITY, OUT_LOG, CusmcError, check
 
 __all__ = ["Context", "MultiVariateNormalDistribution", "MultiVariateTStudentDistribution",
-           "Sampler", "MVN", "MVNPDF", "MVT", "MVTPDF", "metropolis_hastings", "run",
+           "Sampler", "propagate_dev", "initialize_dev", "MVN", "MVNPDF", "MVT", "MVTPDF", "metropolis_hastings", "run",
            "set_seed", "eigenSolver", "CusmcError"]
 
 SQRT3 = 1.7320508075688772  # the reference CPU transform's std-dev inflation
@@ -285,6 +285,31 @@ class Sampler:
                                               int(seed), int(t), int(first), a.numel(),
                                               C.c_void_p(a.data_ptr())))
         return a
+
+
+def propagate_dev(X_prev, a, G, Q, X_out, kind="mvn", nu=0.0, scale=1.0, seed=0, step=1, first=0, ctx=None):
+    """propagate_K on device-resident tensors (src/mcmc.cpp:90-160):
+    X_out[i] = [diag(c)] Q (scale xi) + G X_prev[a[i]] for the rows [first, first + len(X_out)).
+    X_prev: N x d float64 CUDA tensor; a: int32 CUDA tensor of len(X_out) ancestors, or None."""
+    ctx = ctx or default_context()
+    G, Q = _f64(G), _f64(Q)
+    d = X_prev.shape[1]
+    check(_lib.lib().cusmc_propagate_dev(ctx._h, _MVT if kind == "mvt" else _MVN, C.c_float(nu),
+                                         C.c_void_p(X_prev.data_ptr()),
+                                         None if a is None else C.c_void_p(a.data_ptr()), X_prev.shape[0], d,
+                                         _ptr(G), _ptr(Q), float(scale), int(seed), int(step), int(first),
+                                         X_out.shape[0], C.c_void_p(X_out.data_ptr())))
+    return X_out
+
+
+def initialize_dev(m0, Q, X_out, kind="mvn", nu=0.0, scale=1.0, seed=0, first=0, ctx=None):
+    """initialize() draws on a device-resident tensor (src/mcmc.cpp:44-88)."""
+    ctx = ctx or default_context()
+    m0, Q = _f64(m0), _f64(Q)
+    check(_lib.lib().cusmc_initialize_dev(ctx._h, _MVT if kind == "mvt" else _MVN, C.c_float(nu), _ptr(m0),
+                                          _ptr(Q), m0.shape[0], float(scale), int(seed), int(first),
+                                          X_out.shape[0], C.c_void_p(X_out.data_ptr())))
+    return X_out
 
 
 # ---- R-level exports ----------------------------------------------------------------------------

@@ -505,10 +505,26 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
   if (kind != CUSMC_MVN && kind != CUSMC_MVT) return fail(CUSMC_EINVAL, "unknown distribution kind %d", kind);
   if (kind == CUSMC_MVT && !(nu > 0.f)) return fail(CUSMC_EINVAL, "nu = %g must be positive", (double)nu);
   if (d < 1 || !Q) return fail(CUSMC_EINVAL, "bad d or null Q");
-  if (d > 159) return fail(CUSMC_ERANGE, "proposal kernel supports d <= 159 (got %d)", d);
   if (count == 0) return CUSMC_OK;
   if (!X_out_dev) return fail(CUSMC_EINVAL, "null output pointer");
   const size_t dd = (size_t)d * d;
+  if (cusmc::propagate_mfma_supported(d, X_prev_dev, X_out_dev)) {
+    // device image: [frags(Q) | frags(G) | m0], fragments in the MFMA operand order
+    const size_t nf = (size_t)cusmc::mfma_num_frags(d / 16, false) * 64;
+    std::vector<double> img(2 * nf + d, 0.0);
+    cusmc::mfma_pack_frags(Q, d, false, img.data());
+    if (G) cusmc::mfma_pack_frags(G, d, false, img.data() + nf);
+    if (m0) std::copy(m0, m0 + d, img.begin() + 2 * nf);
+    if (int rc = ctx->scratch[4].reserve(img.size() * 8)) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->scratch[4].p, img.data(), img.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // img is a stack-lifetime staging buffer
+    const double *base = (const double *)ctx->scratch[4].p;
+    HIP_TRY(cusmc::launch_propagate_mfma(kind, nu, X_prev_dev, a_dev, base, G ? base + nf : nullptr,
+                                         m0 ? base + 2 * nf : nullptr, d, scale, seed, step, domain, first,
+                                         count, X_out_dev, ctx->num_cus, ctx->stream));
+    return CUSMC_OK;
+  }
+  if (d > 159) return fail(CUSMC_ERANGE, "proposal kernels support d <= 159 or d in {16,32,48,64} (got %d)", d);
   // device image: [Q | G | m0]
   if (int rc = ctx->scratch[4].reserve((2 * dd + d) * 8)) return rc;
   if (int rc = upload_small(ctx, ctx->scratch[4], 0, Q, dd)) return rc;

@@ -260,7 +260,7 @@ def test_resampler_full_size_properties(cs):
 
 # --- draws and the filter ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("d", [2, 5, 8, 33])
+@pytest.mark.parametrize("d", [2, 5, 8, 16, 33, 64])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 5.0), ("mvt", 1.5)])
 def test_draws_match_oracle(cs, oracle, d, dist, nu):
     """Same Philox counters, same transform: the draws agree to rounding (libm vs ocml log/
@@ -276,6 +276,36 @@ def test_draws_match_oracle(cs, oracle, d, dist, nu):
         want, _ = oracle.initialize(300, mu, Q, dist, nu, scale, seed=42, step=6)
         assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
     D.close()
+
+
+@pytest.mark.parametrize("d", [2, 8, 16, 32, 48, 64])
+@pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0)])
+def test_propagate_matches_oracle(cs, oracle, d, dist, nu):
+    """propagate_K (src/mcmc.cpp:112-140): gather by ancestor + G x + Q xi, device-resident, against the
+    oracle on the same Philox counters; d = 16..64 take the MFMA kernel, the others the generic one.
+    Also the shard identity the multi-GPU path relies on: rows [first, first+count) computed alone
+    equal the same rows of the full launch."""
+    import torch
+    rng = np.random.default_rng(d + 17)
+    N = 1000 + 7  # not a multiple of 16
+    Xp = rng.standard_normal((N, d))
+    a = rng.integers(0, N, N).astype(np.uint32)
+    G = 0.9 * np.eye(d) + 0.3 * rng.standard_normal((d, d)) / np.sqrt(d)   # dense, asymmetric
+    Q = oracle.eigen_sqrt(0.2 * spd(rng, d))
+    want = oracle.propagate(Xp, a, G, Q, dist, nu, 1.0, seed=77, step=5)
+    ctx = cs.api.default_context().use_torch_stream()
+    Xd = torch.from_numpy(Xp).cuda()
+    ad = torch.from_numpy(a.astype(np.int32)).cuda()
+    out = torch.empty(N, d, dtype=torch.float64, device="cuda")
+    cs.api.propagate_dev(Xd, ad, G, Q, out, dist, nu, 1.0, seed=77, step=5, ctx=ctx)
+    torch.cuda.synchronize()
+    assert np.allclose(out.cpu().numpy(), want, rtol=1e-9, atol=1e-9)
+    first, count = 333, 401
+    part = torch.empty(count, d, dtype=torch.float64, device="cuda")
+    cs.api.propagate_dev(Xd, ad[first:first + count].contiguous(), G, Q, part, dist, nu, 1.0, seed=77, step=5,
+                         first=first, ctx=ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(part, out[first:first + count])
 
 
 def test_R_level_draws(cs):
