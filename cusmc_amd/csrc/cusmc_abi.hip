@@ -63,6 +63,49 @@ struct DevBuf {
   }
 };
 
+// Small host->device parameter uploads (factor fragments, shift / bias vectors, proposal
+// matrices) go through a ring of pinned host slots: the caller's buffer is consumed by a memcpy
+// into the slot before the call returns, the DMA runs stream-ordered from the slot, and a slot
+// is reused only after the event recorded behind its last DMA has completed.  No stream sync,
+// no dependence on how the runtime treats pageable sources.
+struct StagingRing {
+  static const int kSlots = 8;
+  void *host[kSlots] = {};
+  size_t cap[kSlots] = {};
+  hipEvent_t done[kSlots] = {};
+  bool used[kSlots] = {};
+  int next = 0;
+  int upload(void *dst_dev, const void *src, size_t bytes, hipStream_t stream)
+  {
+    const int i = next;
+    next = (next + 1) % kSlots;
+    if (used[i]) HIP_TRY(hipEventSynchronize(done[i]));
+    if (!done[i]) HIP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    if (bytes > cap[i]) {
+      if (host[i]) (void)hipHostFree(host[i]);
+      host[i] = nullptr;
+      cap[i] = 0;
+      const size_t want = bytes < 65536 ? 65536 : bytes;
+      HIP_TRY(hipHostMalloc(&host[i], want, hipHostMallocDefault));
+      cap[i] = want;
+    }
+    memcpy(host[i], src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst_dev, host[i], bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(done[i], stream));
+    used[i] = true;
+    return CUSMC_OK;
+  }
+  void release()
+  {
+    for (int i = 0; i < kSlots; ++i) {
+      if (used[i]) (void)hipEventSynchronize(done[i]);
+      if (done[i]) (void)hipEventDestroy(done[i]);
+      if (host[i]) (void)hipHostFree(host[i]);
+      host[i] = nullptr; cap[i] = 0; done[i] = nullptr; used[i] = false;
+    }
+  }
+};
+
 }  // namespace
 
 struct cusmc_ctx {
@@ -70,6 +113,7 @@ struct cusmc_ctx {
   int num_cus = 0;
   hipStream_t stream = nullptr;
   DevBuf scratch[6];  // host-pointer entry points: X, out, w, a, small matrices
+  StagingRing ring;  // pinned staging for small parameter uploads
 };
 
 struct cusmc_dist {
@@ -142,16 +186,14 @@ int install_plan(cusmc_dist *dist, int plan, bool tri, const std::vector<double>
     std::vector<double> tmp(padded, 0.0);
     std::copy(shift.begin(), shift.end(), tmp.begin());
     if (int rc = dist->shift.reserve(padded * 8)) return rc;
-    HIP_TRY(hipMemcpyAsync(dist->shift.p, tmp.data(), padded * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // tmp is a stack-lifetime staging buffer
+    if (int rc = ctx->ring.upload(dist->shift.p, tmp.data(), padded * 8, ctx->stream)) return rc;
     dist->plan_shift = shift;
   }
   if (dist->plan_bias != bias || dist->bias.p == nullptr) {
     std::vector<double> tmp(padded, 0.0);
     std::copy(bias.begin(), bias.end(), tmp.begin());
     if (int rc = dist->bias.reserve(padded * 8)) return rc;
-    HIP_TRY(hipMemcpyAsync(dist->bias.p, tmp.data(), padded * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int rc = ctx->ring.upload(dist->bias.p, tmp.data(), padded * 8, ctx->stream)) return rc;
     dist->plan_bias = bias;
   }
   return CUSMC_OK;
@@ -163,14 +205,13 @@ int ensure_frags(cusmc_dist *dist, int kind)
   const int d = dist->d, nb = d / 16;
   const size_t n = kind == 2 ? cusmc::mfma_wide_frag_doubles(nb, dist->plan_tri)
                              : (size_t)cusmc::mfma_num_frags(nb, dist->plan_tri) * 64;
-  std::vector<double> frags(n);
+  std::vector<double> frags(n, 0.0);
   if (kind == 2)
     cusmc::mfma_wide_pack_frags(dist->hostM.data(), d, dist->plan_tri, frags.data());
   else
     cusmc::mfma_pack_frags(dist->hostM.data(), d, dist->plan_tri, frags.data());
   if (int rc = dist->frags.reserve(n * 8)) return rc;
-  HIP_TRY(hipMemcpyAsync(dist->frags.p, frags.data(), n * 8, hipMemcpyHostToDevice, dist->ctx->stream));
-  HIP_TRY(hipStreamSynchronize(dist->ctx->stream));
+  if (int rc = dist->ctx->ring.upload(dist->frags.p, frags.data(), n * 8, dist->ctx->stream)) return rc;
   dist->frags_valid = true;
   dist->frags_kind = kind;
   return CUSMC_OK;
@@ -181,8 +222,7 @@ int ensure_M(cusmc_dist *dist)
   if (dist->M_valid) return CUSMC_OK;
   const size_t n = (size_t)dist->d * dist->d;
   if (int rc = dist->Mdev.reserve(n * 8)) return rc;
-  HIP_TRY(hipMemcpyAsync(dist->Mdev.p, dist->hostM.data(), n * 8, hipMemcpyHostToDevice, dist->ctx->stream));
-  HIP_TRY(hipStreamSynchronize(dist->ctx->stream));
+  if (int rc = dist->ctx->ring.upload(dist->Mdev.p, dist->hostM.data(), n * 8, dist->ctx->stream)) return rc;
   dist->M_valid = true;
   return CUSMC_OK;
 }
@@ -303,6 +343,7 @@ CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &b : ctx->scratch) b.release();
+  ctx->ring.release();
   delete ctx;
   return CUSMC_OK;
 }
@@ -493,8 +534,7 @@ namespace {
 
 int upload_small(cusmc_ctx *ctx, DevBuf &buf, size_t offset_doubles, const double *src, size_t n)
 {
-  HIP_TRY(hipMemcpyAsync((double *)buf.p + offset_doubles, src, n * 8, hipMemcpyHostToDevice, ctx->stream));
-  return CUSMC_OK;
+  return ctx->ring.upload((double *)buf.p + offset_doubles, src, n * 8, ctx->stream);
 }
 
 int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const uint32_t *a_dev,
@@ -516,8 +556,7 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
     if (G) cusmc::mfma_pack_frags(G, d, false, img.data() + nf);
     if (m0) std::copy(m0, m0 + d, img.begin() + 2 * nf);
     if (int rc = ctx->scratch[4].reserve(img.size() * 8)) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->scratch[4].p, img.data(), img.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // img is a stack-lifetime staging buffer
+    if (int rc = ctx->ring.upload(ctx->scratch[4].p, img.data(), img.size() * 8, ctx->stream)) return rc;
     const double *base = (const double *)ctx->scratch[4].p;
     HIP_TRY(cusmc::launch_propagate_mfma(kind, nu, X_prev_dev, a_dev, base, G ? base + nf : nullptr,
                                          m0 ? base + 2 * nf : nullptr, d, scale, seed, step, domain, first,

@@ -66,6 +66,21 @@ def main():
             cusmc_amd.Sampler.metropolis_hastings_dev(w, a, B=B, t=st[0], seed=1, first=0, ctx=ctx)
         t = timed(f, 3 if B >= 1000 else 50, 1)
         rows.append((name, "%.3g steps/s" % (count * B / t), "%.3f ms" % (t * 1e3), "-", "-"))
+    # proposal draws (propagate_K), device-resident
+    for name, N, d, kind, nu in (("propagate MVN 1e6 x d=64", 1_000_000, 64, "mvn", 0.0), ("propagate MVT(4) 1e6 x d=64", 1_000_000, 64, "mvt", 4.0),
+                                 ("propagate MVN 1e6 x d=2", 1_000_000, 2, "mvn", 0.0), ("propagate MVN 1e6 x d=8", 1_000_000, 8, "mvn", 0.0)):
+        Xp = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+        anc = torch.randint(0, N, (N,), dtype=torch.int32, device="cuda", generator=g)
+        out = torch.empty(N, d, dtype=torch.float64, device="cuda")
+        Gm = 0.9 * np.eye(d); Q = 0.3 * np.eye(d)
+        st = [0]
+
+        def f():
+            st[0] += 1
+            cusmc_amd.api.propagate_dev(Xp, anc, Gm, Q, out, kind, nu, 1.0, seed=1, step=st[0], ctx=ctx)
+        t = timed(f, 10, 2)
+        rows.append((name, "%.3g particles/s" % (N / t), "%.1f us" % (t * 1e6), "%.2f TB/s" % (N * (16 * d + 4) / t / 1e12), "-"))
+        del Xp, anc, out
     # filter (host round trip included: that is what run() does)
     for name, N, d, T in (("C3 run() N=1e6 d=2 T=100", 1_000_000, 2, 100), ("run() N=2e5 d=64 T=10", 200_000, 64, 10)):
         I = np.eye(d)
