@@ -65,6 +65,16 @@ def lib():
             raise ImportError(
                 "libcusmc_hip.so is not built (%s). Build it with `make -C cusmc_amd/csrc`; "
                 "there is no CPU fallback." % SO_PATH)
+        # One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 /
+        # libhsa-runtime64; if this library pulls in /opt/rocm's copy first, torch's later
+        # initialisation finds "No HIP GPUs".  Loaded in the other order both share torch's copy.
+        # So when torch is installed (it provides the device tensors and streams of the
+        # device-resident API anyway) it is imported before the first dlopen.
+        if os.environ.get("CUSMC_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(SO_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the ABI and this table drift apart

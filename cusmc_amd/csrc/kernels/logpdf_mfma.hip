@@ -34,12 +34,12 @@ void mfma_pack_frags(const double *M, int d, bool tri, double *frags)
 template <int NB, bool TRI, bool SHIFT>
 static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, const double *frags,
                             const double *shift, const double *bias, const Epilogue &ep,
-                            double *out, int num_cus, hipStream_t stream)
+                            double *out, unsigned *sched, int num_cus, hipStream_t stream)
 {
   constexpr int NFRAG = TRI ? 4 * NB * (NB + 1) / 2 : 4 * NB * NB;
   constexpr bool WREG = TRI && NB <= 4;
   constexpr int THREADS = mfma_threads<NB>();
-  const size_t lds_bytes = (size_t)(32 * NB + 2 + (WREG ? 0 : NFRAG * 64)) * sizeof(double);
+  const size_t lds_bytes = (size_t)(32 * NB + 4 + (WREG ? 0 : NFRAG * 64)) * sizeof(double);
   const long num_tiles = (N + 15) / 16;
   auto kern = logpdf_mfma_kernel<NB, TRI, SHIFT>;
   if (lds_bytes > 64 * 1024) {
@@ -50,23 +50,23 @@ static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, const doubl
   // one persistent workgroup per CU (its waves share the tile counter), fewer when there is
   // less work than that
   long blocks = num_cus;
-  if (blocks > num_tiles) blocks = num_tiles;
+  if (blocks > (num_tiles + 15) / 16) blocks = (num_tiles + 15) / 16;  // a chunk of 16 tiles each
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds_bytes, stream, X, (long)N,
-                     (long)ldx, frags, shift, bias, ep, out, num_tiles);
+                     (long)ldx, frags, shift, bias, ep, out, num_tiles, sched);
   return hipGetLastError();
 }
 
 hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool tri,
                               bool has_shift, const double *frags, const double *shift,
-                              const double *bias, const Epilogue &ep, double *out, int num_cus,
-                              hipStream_t stream)
+                              const double *bias, const Epilogue &ep, double *out, unsigned *sched,
+                              int num_cus, hipStream_t stream)
 {
   if (N <= 0) return hipSuccess;
 #define CUSMC_CASE(nb)                                                                            \
   case nb:                                                                                        \
-    if (!tri) return launch_nb<nb, false, false>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream); \
-    return has_shift ? launch_nb<nb, true, true>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream)  \
-                     : launch_nb<nb, true, false>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream);
+    if (!tri) return launch_nb<nb, false, false>(X, N, ldx, frags, shift, bias, ep, out, sched, num_cus, stream); \
+    return has_shift ? launch_nb<nb, true, true>(X, N, ldx, frags, shift, bias, ep, out, sched, num_cus, stream)  \
+                     : launch_nb<nb, true, false>(X, N, ldx, frags, shift, bias, ep, out, sched, num_cus, stream);
   switch (d / 16) {
     CUSMC_CASE(1)
     CUSMC_CASE(2)

@@ -54,7 +54,8 @@ __device__ __forceinline__ double finish(double q, const Epilogue &ep)
 // !TRI = affine form:   z = bias + M x,    M dense, no shift                (reweight_G)
 // SHIFT = false drops the subtraction when the shift vector is all zeros.
 // ABL is for scripts/calib/ablate.hip only (0 in the library): 1 = no global loads inside the tile
-// loop, 2 = no MFMAs, 3 = no cross-lane reduction, 4 = clock stamps.  It exists to attribute time.
+// loop, 2 = no MFMAs, 3 = no cross-lane reduction, 4 = clock stamps, 5 = 1 + 4, 6 = static tile
+// assignment instead of the global chunk queue.  It exists to attribute time.
 //
 // Instruction budget.  Measured on gfx950 (scripts/calib/calib.hip): while a v_mfma_f64 runs
 // (64.8 cycles) NO other wave of that SIMD issues VALU work -- an MFMA wave plus an integer-VALU
@@ -67,11 +68,19 @@ __device__ __forceinline__ double finish(double q, const Epilogue &ep)
 // adds and one compare per tile.
 //
 // Work distribution.  ONE workgroup per CU, as many waves as the register file admits
-// (mfma_threads<NB>()).  Workgroup b owns tiles b, b+G, b+2G, ... (G = grid size) and its waves
-// pull the next one from a counter in LDS.  Static round-robin over waves loses ~10 %: the
-// older of two waves on a SIMD wins issue arbitration, finishes its share early and leaves the
-// younger one to run alone (measured: 78 us vs 87 us wave lifetimes at d = 64).  The counter is
-// workgroup-local, so there is no global state to reset between launches.
+// (mfma_threads<NB>()).  Two levels, both dynamic:
+//   * waves pull tiles from their workgroup's current CHUNK (16 consecutive tiles) through one
+//     packed 64-bit LDS word {chunk base, next offset} -- a single ds_add_rtn_u64 per tile.
+//     Static round-robin over waves loses ~10 %: the older of two waves on a SIMD wins issue
+//     arbitration, finishes its share early and leaves the younger one to run alone (measured:
+//     78 us vs 87 us wave lifetimes at d = 64);
+//   * workgroups pull chunks from ONE global counter (`sched[0]`): ~3.7k atomics per launch on
+//     the headline shape, ~40 per us, under the ~88 per us a single word sustains
+//     (MI355X_MICROARCH.md, dequeue).  The first chunk of a workgroup is static (b * CH), the next
+//     one is always requested a chunk ahead, so no wave waits for the global atomic.  Static
+//     tile -> workgroup assignment left workgroup lifetimes spread over 83..93 us of a 94 us launch;
+//   * the last workgroup to finish (counted in `sched[1]`) resets both words, so launches need no
+//     memset; `sched` is zeroed once when the context is created.
 //
 // Factor residency.  WREG (triangular, d <= 64): each lane keeps its 2*NB*(NB+1) factor values in
 // registers for the whole kernel (80 VGPRs at d = 64) -- the tile loop then has no LDS reads at
@@ -86,16 +95,24 @@ template <int NB, bool TRI, bool SHIFT, int ABL = 0>
 __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     const double *__restrict__ X, long N, long ldx, const double *__restrict__ frags,
     const double *__restrict__ shift, const double *__restrict__ bias, Epilogue ep,
-    double *__restrict__ out, long num_tiles)
+    double *__restrict__ out, long num_tiles, unsigned *__restrict__ sched)
 {
   constexpr int THREADS = mfma_threads<NB>();
+  constexpr unsigned CH = 16;  // tiles per chunk
   constexpr int NFRAG = TRI ? 4 * NB * (NB + 1) / 2 : 4 * NB * NB;
   constexpr bool WREG = TRI && NB <= 4;
   extern __shared__ double lds[];
   double *sShift = lds;              // 16*NB
   double *sBias = sShift + 16 * NB;  // 16*NB
-  int *sNext = reinterpret_cast<int *>(sBias + 16 * NB);  // the workgroup's tile counter (+pad)
-  double *sF = sBias + 16 * NB + 2;  // NFRAG x 64 (only when !WREG)
+  // scheduler words: sCur = {chunk base tile : 32 | next offset : 32}; sCtl[0] = base of the
+  // prefetched next chunk, sCtl[1] = number of chunks published so far, sCtl[2] = chunks swapped in
+  unsigned long long *sCur = reinterpret_cast<unsigned long long *>(sBias + 16 * NB);
+  unsigned *sCtl = reinterpret_cast<unsigned *>(sBias + 16 * NB + 1);
+  // (relaxed workgroup-scope atomics, not `volatile`: volatile LDS accesses make the memory
+  // legaliser drain vmcnt as well, which costs the tile loop its counted waits)
+  auto ctl_load = [&](int i) { return __hip_atomic_load(&sCtl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto ctl_store = [&](int i, unsigned v) { __hip_atomic_store(&sCtl[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  double *sF = sBias + 16 * NB + 4;  // NFRAG x 64 (only when !WREG)
 
   if (!WREG) {
     // Stage the factor: all of a chunk's 16-byte loads are issued before the first LDS write,
@@ -122,14 +139,18 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     sShift[threadIdx.x] = shift[threadIdx.x];
     sBias[threadIdx.x] = bias[threadIdx.x];
   }
-  if (threadIdx.x == 0) *sNext = 0;
+  const long G = gridDim.x;
+  if (threadIdx.x == 0) {
+    *sCur = (unsigned long long)((unsigned)blockIdx.x * CH) << 32;  // first chunk: static
+    const unsigned g = __hip_atomic_fetch_add(&sched[0], CH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sCtl[0] = (unsigned)G * CH + g;  // second chunk, requested before any work starts
+    sCtl[2] = 0;
+    sCtl[1] = 1;
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int p = lane & 15, h = lane >> 4;
-  // tiles of this workgroup: blockIdx.x + k * gridDim.x, k < my_tiles
-  const long G = gridDim.x;
-  const int my_tiles = (int)((num_tiles - 1 - (long)blockIdx.x) / G) + 1;  // grid <= num_tiles
   const long last = num_tiles - 1;
   const long tile_bytes = 128 * ldx;  // 16 rows
   // per-lane byte offset inside a tile; in the last tile rows past N re-read row N-1 (their
@@ -138,19 +159,61 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   const unsigned lane_off = (unsigned)((long)p * ldx + 2 * h) * 8u;
   const unsigned lane_off_last = (unsigned)((long)(p < tail_rows ? p : tail_rows - 1) * ldx + 2 * h) * 8u;
 
-  // next tile index of this workgroup, wave-uniform (one LDS atomic per wave per tile)
-  auto grab = [&]() -> int {
-    int k = 0;
-    if (lane == 0) k = atomicAdd(sNext, 1);
-    return __builtin_amdgcn_readfirstlane(k);
+  // Next tile for this wave (wave-uniform); >= num_tiles means the work is exhausted.  The wave
+  // that draws offset == CH swaps in the prefetched chunk and requests the one after it; waves
+  // that draw a larger offset retry (bounded) until the swap has happened.  All bookkeeping is
+  // 32-bit and scalar (64-bit scalar compares do not exist and would fall back to the VALU).
+  const unsigned nt = (unsigned)num_tiles;  // launch_nb() guarantees num_tiles < 2^31
+  auto grab = [&]() -> unsigned {
+    if (ABL == 6) {  // calibration only: the static tile -> workgroup split (tiles b, b+G, b+2G, ...)
+      unsigned long long old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(sCur, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
+      const unsigned long long t = (unsigned long long)blockIdx.x + (unsigned long long)k * (unsigned)G;
+      return t < nt ? (unsigned)t : nt;
+    }
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      unsigned long long old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(sCur, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)(old >> 32));
+      const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
+      if (off < CH) return base + off;
+      if (base >= nt) return nt;  // exhausted chunk past the end: done
+      if (off == CH) {
+        const unsigned j = ctl_load(2);
+        for (int w2 = 0; ctl_load(1) != j + 1 && w2 < (1 << 22); ++w2) __builtin_amdgcn_s_sleep(1);
+        const unsigned nb = ctl_load(0);
+        ctl_store(2, j + 1);
+        if (lane == 0)
+          __hip_atomic_exchange(sCur, (unsigned long long)nb << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // The request for the chunk after next is a returning global atomic.  As a builtin it makes
+        // hipcc give up counted vmcnt in the tile loop (loads and returning atomics may complete
+        // out of order); as inline asm with its own wait it is invisible to that pass, and an
+        // uncounted operation in flight only makes the compiler's counted waits wait for one load
+        // more, never fewer.  Executed once per 16 tiles.
+        unsigned g = 0;
+        if (lane == 0 && nb < nt) {
+          const unsigned zero = 0, inc = CH;
+          asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(g)
+                       : "v"(zero), "v"(inc), "s"(sched)
+                       : "memory");
+        }
+        g = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+        ctl_store(0, nb < nt ? (unsigned)G * CH + g : nb);  // past the end: stay there
+        ctl_store(1, j + 2);
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    return nt;  // unreachable short of a scheduler fault; never hang the GPU
   };
-  auto tile_of = [&](int k) -> long { return (long)blockIdx.x + (long)k * G; };
 
-  // loads tile k; past the end it re-reads the workgroup's first tile (an L2 hit, result unused):
-  // a branch around the prefetch would make hipcc's s_waitcnt placement assume the no-prefetch
-  // path and wait for the prefetched loads at the head of every tile.
-  auto load_tile = [&](int k, v2d(&a)[NB][2]) {
-    const long t = tile_of(k < my_tiles ? k : 0);
+  // loads tile tt; past the end it re-reads the workgroup's first tile (an L2 hit, result
+  // unused): a branch around the prefetch would make hipcc's s_waitcnt placement assume the
+  // no-prefetch path and wait for the prefetched loads at the head of every tile.
+  auto load_tile = [&](unsigned tt, v2d(&a)[NB][2]) {
+    const long t = tt < nt ? tt : blockIdx.x * CH;
     const char *base = reinterpret_cast<const char *>(X) + t * tile_bytes;  // scalar
     const unsigned off = t == last ? lane_off_last : lane_off;
 #pragma unroll
@@ -170,8 +233,8 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   // as in-loop ds_read_b64.
   int lds_lane = lane;
 
-  auto compute_tile = [&](int k, const v2d(&a_in)[NB][2]) {
-    const long t = tile_of(k);
+  auto compute_tile = [&](unsigned tu, const v2d(&a_in)[NB][2]) {
+    const long t = tu;
     v4d acc[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
@@ -254,43 +317,52 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   if (ABL == 4 || ABL == 5) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   int done = 0;
 
-  int k0 = grab();
-  if (k0 < my_tiles) {
+  unsigned k0 = grab();
+  if (k0 < nt) {
     if constexpr (NB <= 4) {
       // Three register sets in rotation: while one tile runs on the matrix cores the loads of
       // the next TWO are in flight (16 KB per wave).  No register copies: the loop is unrolled
       // by three with the roles renamed.
       v2d a0[NB][2], a1[NB][2], a2[NB][2];
-      int k1 = grab();
+      unsigned k1 = grab();
       load_tile(k0, a0);
       load_tile(k1, a1);
       while (true) {
-        const int k2 = grab();
+        const unsigned k2 = grab();
         if (ABL != 1 && ABL != 5) load_tile(k2, a2);
         compute_tile(k0, a0); ++done;
-        if (k1 >= my_tiles) break;
+        if (k1 >= nt) break;
         k0 = grab();
         if (ABL != 1 && ABL != 5) load_tile(k0, a0);
         compute_tile(k1, (ABL == 1 || ABL == 5) ? a0 : a1); ++done;
-        if (k2 >= my_tiles) break;
+        if (k2 >= nt) break;
         k1 = grab();
         if (ABL != 1 && ABL != 5) load_tile(k1, a1);
         compute_tile(k2, (ABL == 1 || ABL == 5) ? a0 : a2); ++done;
-        if (k0 >= my_tiles) break;
+        if (k0 >= nt) break;
       }
     } else {  // d >= 96: two sets (three would not fit the register file)
       v2d a0[NB][2], a1[NB][2];
       load_tile(k0, a0);
       while (true) {
-        const int k1 = grab();
+        const unsigned k1 = grab();
         load_tile(k1, a1);
         compute_tile(k0, a0);
-        if (k1 >= my_tiles) break;
+        if (k1 >= nt) break;
         k0 = grab();
         load_tile(k0, a0);
         compute_tile(k1, a1);
-        if (k0 >= my_tiles) break;
+        if (k0 >= nt) break;
       }
+    }
+  }
+  // the last workgroup out re-arms the scheduler for the next launch
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned dn = __hip_atomic_fetch_add(&sched[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dn == (unsigned)G - 1) {
+      __hip_atomic_store(&sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sched[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if ((ABL == 4 || ABL == 5) && lane == 0) {

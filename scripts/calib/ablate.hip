@@ -7,10 +7,12 @@
 #include <cstdio>
 #include <time.h>
 #include <vector>
+#include <algorithm>
 
 #include "../../cusmc_amd/csrc/kernels/logpdf_mfma_kernel.h"
 
 using namespace cusmc;
+static unsigned *g_sched = nullptr;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -19,16 +21,16 @@ static float run(const double *X, long N, const double *frags, const double *shi
                  double *out, int blocks, int reps)
 {
   Epilogue ep{-10.0, 0, 0, 0, 0};
-  const size_t lds = (size_t)(32 * 4 + 2) * 8;
+  const size_t lds = (size_t)(32 * 4 + 4) * 8;
   const long tiles = (N + 15) / 16;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, frags, shift, bias, ep, out, tiles);
+    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, frags, shift, bias, ep, out, tiles, g_sched);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
   for (int i = 0; i < reps; ++i)
-    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, frags, shift, bias, ep, out, tiles);
+    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, frags, shift, bias, ep, out, tiles, g_sched);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   return ms / reps * 1e3f;
@@ -42,6 +44,7 @@ int main()
   for (auto &v : hX) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) - (1 << 23)) * (1.0 / (1 << 22)); }
   for (int i = 0; i < d; ++i) for (int j = 0; j <= i; ++j) { s = s * 1664525u + 1013904223u; M[i * d + j] = (i == j) + 0.1 * ((int)(s >> 8) - (1 << 23)) * (1.0 / (1 << 23)); }
   mfma_pack_frags(M.data(), d, true, frags.data());
+  CK(hipMalloc(&g_sched, 64)); CK(hipMemset(g_sched, 0, 64));
   double *X, *F, *sh, *bi, *out;
   CK(hipMalloc(&X, hX.size() * 8)); CK(hipMalloc(&F, frags.size() * 8)); CK(hipMalloc(&sh, 512)); CK(hipMalloc(&bi, 512)); CK(hipMalloc(&out, N * 8 + 16 * 4096 * 8));
   CK(hipMemcpy(X, hX.data(), hX.size() * 8, hipMemcpyHostToDevice));
@@ -49,7 +52,7 @@ int main()
   CK(hipMemcpy(sh, z.data(), 512, hipMemcpyHostToDevice)); CK(hipMemcpy(bi, z.data(), 512, hipMemcpyHostToDevice));
   {  // sustained vs isolated launches of the product variant at 2 blocks/CU
     Epilogue ep{-10.0, 0, 0, 0, 0};
-    const size_t lds = (size_t)(32 * 4 + 2) * 8;
+    const size_t lds = (size_t)(32 * 4 + 4) * 8;
     const long tiles = (N + 15) / 16;
     int occ = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, logpdf_mfma_kernel<4, true, false, 0>, 512, lds);
@@ -60,7 +63,7 @@ int main()
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
         for (int i = 0; i < reps; ++i)
-          hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+          hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles, g_sched);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         printf("blocks %d, %4d back-to-back launches: %.1f us each\n", blocks, reps, ms / reps * 1e3);
@@ -70,7 +73,7 @@ int main()
         (void)hipDeviceSynchronize();
         struct timespec ts = {0, 3000000}; nanosleep(&ts, nullptr);
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+        hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0>), dim3(blocks), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles, g_sched);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1); tot += ms;
       }
@@ -79,11 +82,11 @@ int main()
   }
   for (int mode = 0; mode < 2; ++mode) {  // in-kernel clock: full kernel, then the no-loads variant
     Epilogue ep{-10.0, 0, 0, 0, 0};
-    const size_t lds = (size_t)(32 * 4 + 2) * 8;
+    const size_t lds = (size_t)(32 * 4 + 4) * 8;
     const long tiles = (N + 15) / 16;
     for (int i = 0; i < 300; ++i)
-      if (mode == 0) hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 4>), dim3(256), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
-      else hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 5>), dim3(256), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+      if (mode == 0) hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 4>), dim3(256), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles, g_sched);
+      else hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 5>), dim3(256), dim3(512), lds, 0, X, N, 64L, F, sh, bi, ep, out, tiles, g_sched);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st(3 * 2048);
     CK(hipMemcpy(st.data(), out + tiles * 16, st.size() * 8, hipMemcpyDeviceToHost));
@@ -104,6 +107,15 @@ int main()
     }
     printf("[%s] in-kernel clock (300 launches)", mode ? "no-loads" : "full"); printf(": %.2f GHz; wave lifetime %.1f us mean, %.1f min, %.1f max\n",
            csum / rsum * 0.1, rsum / 2048 / 100.0, rmin / 100.0, rmax / 100.0);
+  }
+  {  // A/B in one process, interleaved rounds: global chunk queue (product) vs static split
+    std::vector<float> a, b;
+    for (int round = 0; round < 12; ++round) {
+      a.push_back(run<0>(X, N, F, sh, bi, out, 256, 100));
+      b.push_back(run<6>(X, N, F, sh, bi, out, 256, 100));
+    }
+    std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+    printf("A/B 12 x 100 launches: dynamic queue median %.1f min %.1f | static split median %.1f min %.1f (us)\n", a[6], a[0], b[6], b[0]);
   }
   printf("blocks/CU |  full  | no-loads | no-mfma | no-epilogue-reduce   (us per launch, N=1e6 d=64)\n");
   for (int per : {1}) {
