@@ -132,8 +132,9 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500,
+                    help="the clock governor needs ~50 ms of load to settle (profiles/r01_calibration.txt)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC traffic passes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
