@@ -114,7 +114,6 @@ struct cusmc_ctx {
   hipStream_t stream = nullptr;
   DevBuf scratch[6];  // host-pointer entry points: X, out, w, a, small matrices
   StagingRing ring;  // pinned staging for small parameter uploads
-  DevBuf sched;      // work-queue words of the log-pdf kernel (zeroed once; the kernel re-arms them)
 };
 
 struct cusmc_dist {
@@ -247,7 +246,7 @@ int run_logpdf(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx, in
     if (int rc = ensure_frags(dist, 1)) return rc;
     HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan_tri, has_shift, (const double *)dist->frags.p,
                                       (const double *)dist->shift.p, (const double *)dist->bias.p,
-                                      ep, out_dev, (unsigned *)ctx->sched.p, ctx->num_cus, ctx->stream));
+                                      ep, out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
   if (!cusmc::generic_supported(d))
@@ -334,10 +333,6 @@ CUSMC_EXPORT int cusmc_ctx_create(int device, cusmc_ctx **out)
   if (!ctx) return fail(CUSMC_EINVAL, "out of host memory");
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
-  if (ctx->sched.reserve(64) != CUSMC_OK || hipMemset(ctx->sched.p, 0, 64) != hipSuccess) {
-    delete ctx;
-    return fail(CUSMC_EHIP, "could not allocate the scheduler words");
-  }
   *out = ctx;
   return CUSMC_OK;
 }
@@ -349,7 +344,6 @@ CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &b : ctx->scratch) b.release();
   ctx->ring.release();
-  ctx->sched.release();
   delete ctx;
   return CUSMC_OK;
 }

@@ -31,42 +31,45 @@ void mfma_pack_frags(const double *M, int d, bool tri, double *frags)
         }
 }
 
-template <int NB, bool TRI, bool SHIFT>
+template <int NB, bool TRI, bool SHIFT, bool LOGMVN>
 static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, const double *frags,
                             const double *shift, const double *bias, const Epilogue &ep,
-                            double *out, unsigned *sched, int num_cus, hipStream_t stream)
+                            double *out, int num_cus, hipStream_t stream)
 {
   constexpr int NFRAG = TRI ? 4 * NB * (NB + 1) / 2 : 4 * NB * NB;
-  constexpr bool WREG = TRI && NB <= 4;
+  constexpr bool WREG = mfma_factor_in_regs<NB, TRI>();
   constexpr int THREADS = mfma_threads<NB>();
   const size_t lds_bytes = (size_t)(32 * NB + 4 + (WREG ? 0 : NFRAG * 64)) * sizeof(double);
   const long num_tiles = (N + 15) / 16;
-  auto kern = logpdf_mfma_kernel<NB, TRI, SHIFT>;
+  auto kern = logpdf_mfma_kernel<NB, TRI, SHIFT, 0, LOGMVN>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  // one persistent workgroup per CU (its waves share the tile counter), fewer when there is
+  // one persistent workgroup per CU (its waves share the round counter), fewer when there is
   // less work than that
   long blocks = num_cus;
-  if (blocks > (num_tiles + 15) / 16) blocks = (num_tiles + 15) / 16;  // a chunk of 16 tiles each
+  if (blocks > (num_tiles + 15) / 16) blocks = (num_tiles + 15) / 16;  // >= 16 tiles each
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds_bytes, stream, X, (long)N,
-                     (long)ldx, frags, shift, bias, ep, out, num_tiles, sched);
+                     (long)ldx, frags, shift, bias, ep, out, num_tiles);
   return hipGetLastError();
 }
 
 hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool tri,
                               bool has_shift, const double *frags, const double *shift,
-                              const double *bias, const Epilogue &ep, double *out, unsigned *sched,
-                              int num_cus, hipStream_t stream)
+                              const double *bias, const Epilogue &ep, double *out, int num_cus,
+                              hipStream_t stream)
 {
   if (N <= 0) return hipSuccess;
+  const bool logmvn = ep.kind == CUSMC_MVN && !ep.out_density;
+#define CUSMC_EPI(nb, t, s)                                                                       \
+  (logmvn ? launch_nb<nb, t, s, true>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream) \
+          : launch_nb<nb, t, s, false>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream))
 #define CUSMC_CASE(nb)                                                                            \
   case nb:                                                                                        \
-    if (!tri) return launch_nb<nb, false, false>(X, N, ldx, frags, shift, bias, ep, out, sched, num_cus, stream); \
-    return has_shift ? launch_nb<nb, true, true>(X, N, ldx, frags, shift, bias, ep, out, sched, num_cus, stream)  \
-                     : launch_nb<nb, true, false>(X, N, ldx, frags, shift, bias, ep, out, sched, num_cus, stream);
+    if (!tri) return CUSMC_EPI(nb, false, false);                                                 \
+    return has_shift ? CUSMC_EPI(nb, true, true) : CUSMC_EPI(nb, true, false);
   switch (d / 16) {
     CUSMC_CASE(1)
     CUSMC_CASE(2)
@@ -76,6 +79,7 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
     CUSMC_CASE(8)
   }
 #undef CUSMC_CASE
+#undef CUSMC_EPI
   return hipErrorInvalidValue;
 }
 

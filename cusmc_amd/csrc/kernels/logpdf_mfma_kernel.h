@@ -53,9 +53,14 @@ __device__ __forceinline__ double finish(double q, const Epilogue &ep)
 // TRI  = centred form:  z = W (x - shift), W lower triangular, no bias      (pdf(y, F))
 // !TRI = affine form:   z = bias + M x,    M dense, no shift                (reweight_G)
 // SHIFT = false drops the subtraction when the shift vector is all zeros.
+// LOGMVN = true fixes the epilogue to the MVN log-density (lognorm - q/2) at compile time: the
+// run-time epilogue (Student-t log1p, optional exp) costs ~30 VGPRs of polynomial constants that
+// stay live across the tile loop, and at d = 64 the loop owns the whole register file (80 factor +
+// 96 operand + 32 accumulator VGPRs) -- with them hipcc spilled one operand pair and drained
+// vmcnt to reload it on every third tile.
 // ABL is for scripts/calib/ablate.hip only (0 in the library): 1 = no global loads inside the tile
-// loop, 2 = no MFMAs, 3 = no cross-lane reduction, 4 = clock stamps, 5 = 1 + 4, 6 = static tile
-// assignment instead of the global chunk queue.  It exists to attribute time.
+// loop, 2 = no MFMAs, 3 = no cross-lane reduction, 4 = clock stamps, 5 = 1 + 4.  It exists to
+// attribute time.
 //
 // Instruction budget.  Measured on gfx950 (scripts/calib/calib.hip): while a v_mfma_f64 runs
 // (64.8 cycles) NO other wave of that SIMD issues VALU work -- an MFMA wave plus an integer-VALU
@@ -68,88 +73,122 @@ __device__ __forceinline__ double finish(double q, const Epilogue &ep)
 // adds and one compare per tile.
 //
 // Work distribution.  ONE workgroup per CU, as many waves as the register file admits
-// (mfma_threads<NB>()).  Two levels, both dynamic:
-//   * waves pull tiles from their workgroup's current CHUNK (16 consecutive tiles) through one
-//     packed 64-bit LDS word {chunk base, next offset} -- a single ds_add_rtn_u64 per tile.
-//     Static round-robin over waves loses ~10 %: the older of two waves on a SIMD wins issue
-//     arbitration, finishes its share early and leaves the younger one to run alone (measured:
-//     78 us vs 87 us wave lifetimes at d = 64);
-//   * workgroups pull chunks from ONE global counter (`sched[0]`): ~3.7k atomics per launch on
-//     the headline shape, ~40 per us, under the ~88 per us a single word sustains
-//     (MI355X_MICROARCH.md, dequeue).  The first chunk of a workgroup is static (b * CH), the next
-//     one is always requested a chunk ahead, so no wave waits for the global atomic.  Static
-//     tile -> workgroup assignment left workgroup lifetimes spread over 83..93 us of a 94 us launch;
-//   * the last workgroup to finish (counted in `sched[1]`) resets both words, so launches need no
-//     memset; `sched` is zeroed once when the context is created.
+// (mfma_threads<NB>()).
+//   * Tiles are dealt to workgroups round-robin: workgroup b owns tiles b, b + G, b + 2G, ...  At
+//     any moment the G workgroups stream one contiguous ~2 MB window of X.  Handing each workgroup
+//     chunks of 16 CONSECUTIVE tiles from a global queue instead -- round 1's first scheduler --
+//     measured 2 - 4.5 us per launch slower (same box, same build, scripts/calib/ablate.hip): each
+//     chunk request cost its wave a full s_waitcnt vmcnt(0), i.e. the HBM latency under load with
+//     nothing prefetched behind it, and 256 scattered 128 KB streams use HBM less well than one
+//     window.
+//   * Inside a workgroup the waves pull their next tile through one packed 64-bit LDS word
+//     {end, next} -- a single ds_add_rtn_u64 per tile.  Static round-robin over WAVES loses ~10 %:
+//     the older of two waves on a SIMD wins issue arbitration, finishes its share early and leaves
+//     the younger one to run alone (measured: 78 us vs 87 us wave lifetimes at d = 64).
+//   * Nothing is dynamic ACROSS workgroups.  Queueing the last eighth of the rounds (chunks of 16,
+//     then 8 tiles, drawn with scalar s_atomic_add ... glc so the drawing wave keeps its vector
+//     loads in flight -- gfx950 executes scalar atomics coherently across XCDs at ~87 per us per
+//     word, scripts/calib/satomic.hip) measured 1.0 us SLOWER than dealing everything, although
+//     workgroup lifetimes differ by ~8 % from launch to launch: a wave always has two tiles
+//     prefetched, so whoever draws last still finishes ~2 tiles after the queue runs dry.
 //
 // Factor residency.  WREG (triangular, d <= 64): each lane keeps its 2*NB*(NB+1) factor values in
 // registers for the whole kernel (80 VGPRs at d = 64) -- the tile loop then has no LDS reads at
 // all.  Otherwise the factor is staged once per workgroup in LDS and read one k-step ahead.
+//
+// Things that were tried on the prologue and the loop shape and measured SLOWER (ablate.hip quick
+// mode, same box): touching the first tiles' cache lines before the factor loads (+2.3 us: 64
+// distinct lines per instruction swamp the L1 miss queue and the factor loads sit behind them);
+// a single-exit tile loop with guarded computes, which gives textbook counted waits (+1.6 us);
+// non-temporal output stores (+0.3 us).
 template <int NB>
 __host__ __device__ constexpr int mfma_threads()
 {
+#ifdef EXP_THREADS4  // calibration builds only (scripts/calib/ablate.hip)
+  if (NB == 4) return EXP_THREADS4;
+#endif
   return NB == 1 ? 1024 : NB == 2 ? 768 : NB <= 4 ? 512 : 256;
 }
+template <int NB, bool TRI>
+__host__ __device__ constexpr bool mfma_factor_in_regs()
+{
+#ifdef EXP_LDSW
+  return false;
+#else
+  return TRI && NB <= 4;
+#endif
+}
+template <int NB, bool SHIFT>
+__host__ __device__ constexpr int mfma_sets()  // operand register sets in rotation
+{
+#ifdef EXP_SETS
+  return NB <= 4 ? EXP_SETS : 2;
+#else
+  // Two sets (one tile in flight behind the one being multiplied) beat three at every d <= 64
+  // without a shift: 91.2 vs 94.6 us at d = 64, 93.2 vs 95.1 at d = 32 (interleaved runs on one
+  // box, scripts/logpdf_sweep.py).  2048 waves x 2 tiles is already 32 MB of X in flight, more
+  // than the HBM latency-bandwidth product needs, and a wider window of open addresses costs DRAM
+  // locality.  The shifted form at d >= 48 is the exception (92.6 vs 98.7 us at d = 48): its
+  // per-step subtractions lengthen a tile enough for the deeper prefetch to pay.  d >= 96 has no
+  // registers for a third set.
+  return SHIFT && (NB == 3 || NB == 4) ? 3 : 2;
+#endif
+}
 
-template <int NB, bool TRI, bool SHIFT, int ABL = 0>
+template <int NB, bool TRI, bool SHIFT, int ABL = 0, bool LOGMVN = false>
 __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     const double *__restrict__ X, long N, long ldx, const double *__restrict__ frags,
     const double *__restrict__ shift, const double *__restrict__ bias, Epilogue ep,
-    double *__restrict__ out, long num_tiles, unsigned *__restrict__ sched)
+    double *__restrict__ out, long num_tiles)
 {
   constexpr int THREADS = mfma_threads<NB>();
-  constexpr unsigned CH = 16;  // tiles per chunk
+  constexpr bool STAMP = ABL == 4 || ABL == 5;
+  constexpr bool NOLOAD = ABL == 1 || ABL == 5;
+  unsigned long long stamp_entry = 0;
+  if (STAMP) stamp_entry = __builtin_amdgcn_s_memrealtime();
   constexpr int NFRAG = TRI ? 4 * NB * (NB + 1) / 2 : 4 * NB * NB;
-  constexpr bool WREG = TRI && NB <= 4;
+  constexpr bool WREG = mfma_factor_in_regs<NB, TRI>();
   extern __shared__ double lds[];
   double *sShift = lds;              // 16*NB
   double *sBias = sShift + 16 * NB;  // 16*NB
-  // scheduler words: sCur = {chunk base tile : 32 | next offset : 32}; sCtl[0] = base of the
-  // prefetched next chunk, sCtl[1] = number of chunks published so far, sCtl[2] = chunks swapped in
-  unsigned long long *sCur = reinterpret_cast<unsigned long long *>(sBias + 16 * NB);
-  unsigned *sCtl = reinterpret_cast<unsigned *>(sBias + 16 * NB + 1);
-  // (relaxed workgroup-scope atomics, not `volatile`: volatile LDS accesses make the memory
+  // sNext: the workgroup's round counter (tile b + k*G is round k), one ds_add_rtn_u32 per tile.
+  // (a relaxed workgroup-scope atomic, not `volatile`: volatile LDS accesses make the memory
   // legaliser drain vmcnt as well, which costs the tile loop its counted waits)
-  auto ctl_load = [&](int i) { return __hip_atomic_load(&sCtl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  auto ctl_store = [&](int i, unsigned v) { __hip_atomic_store(&sCtl[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  unsigned *sNext = reinterpret_cast<unsigned *>(sBias + 16 * NB);
   double *sF = sBias + 16 * NB + 4;  // NFRAG x 64 (only when !WREG)
 
   if (!WREG) {
     // Stage the factor: all of a chunk's 16-byte loads are issued before the first LDS write,
     // so the prologue costs one memory round trip per chunk, not one per element.
     constexpr int NV = NFRAG * 32;  // 16-byte elements
-    constexpr int CH = 8;
+    constexpr int SC = 8;
     const v2d *g = reinterpret_cast<const v2d *>(frags);
     v2d *l = reinterpret_cast<v2d *>(sF);
-    for (int base = 0; base < NV; base += CH * THREADS) {
-      v2d tmp[CH];
+    for (int base = 0; base < NV; base += SC * THREADS) {
+      v2d tmp[SC];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
+      for (int c = 0; c < SC; ++c) {
         const int i = base + c * THREADS + (int)threadIdx.x;
         if (i < NV) tmp[c] = g[i];
       }
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
+      for (int c = 0; c < SC; ++c) {
         const int i = base + c * THREADS + (int)threadIdx.x;
         if (i < NV) l[i] = tmp[c];
       }
     }
   }
-  if (threadIdx.x < 16 * NB) {
+  if ((SHIFT || !TRI) && threadIdx.x < 16 * NB) {  // (a cold miss in front of the barrier otherwise)
     sShift[threadIdx.x] = shift[threadIdx.x];
     sBias[threadIdx.x] = bias[threadIdx.x];
   }
-  const long G = gridDim.x;
-  if (threadIdx.x == 0) {
-    *sCur = (unsigned long long)((unsigned)blockIdx.x * CH) << 32;  // first chunk: static
-    const unsigned g = __hip_atomic_fetch_add(&sched[0], CH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sCtl[0] = (unsigned)G * CH + g;  // second chunk, requested before any work starts
-    sCtl[2] = 0;
-    sCtl[1] = 1;
-  }
-  __syncthreads();
 
+  const unsigned G = gridDim.x;
   const int lane = threadIdx.x & 63;
+  const unsigned nt = (unsigned)num_tiles;  // launch_nb() guarantees num_tiles < 2^31
+  const unsigned rounds = (nt + G - 1) / G;
+  if (threadIdx.x == 0) *sNext = 0;
+
   const int p = lane & 15, h = lane >> 4;
   const long last = num_tiles - 1;
   const long tile_bytes = 128 * ldx;  // 16 rows
@@ -159,61 +198,21 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   const unsigned lane_off = (unsigned)((long)p * ldx + 2 * h) * 8u;
   const unsigned lane_off_last = (unsigned)((long)(p < tail_rows ? p : tail_rows - 1) * ldx + 2 * h) * 8u;
 
-  // Next tile for this wave (wave-uniform); >= num_tiles means the work is exhausted.  The wave
-  // that draws offset == CH swaps in the prefetched chunk and requests the one after it; waves
-  // that draw a larger offset retry (bounded) until the swap has happened.  All bookkeeping is
-  // 32-bit and scalar (64-bit scalar compares do not exist and would fall back to the VALU).
-  const unsigned nt = (unsigned)num_tiles;  // launch_nb() guarantees num_tiles < 2^31
+  // Next tile for this wave (wave-uniform); nt means the workgroup's share is exhausted.  Scalar
+  // 32-bit arithmetic (64-bit scalar compares do not exist and would fall back to the VALU).
   auto grab = [&]() -> unsigned {
-    if (ABL == 6) {  // calibration only: the static tile -> workgroup split (tiles b, b+G, b+2G, ...)
-      unsigned long long old = 0;
-      if (lane == 0) old = __hip_atomic_fetch_add(sCur, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
-      const unsigned long long t = (unsigned long long)blockIdx.x + (unsigned long long)k * (unsigned)G;
-      return t < nt ? (unsigned)t : nt;
-    }
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-      unsigned long long old = 0;
-      if (lane == 0) old = __hip_atomic_fetch_add(sCur, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)(old >> 32));
-      const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
-      if (off < CH) return base + off;
-      if (base >= nt) return nt;  // exhausted chunk past the end: done
-      if (off == CH) {
-        const unsigned j = ctl_load(2);
-        for (int w2 = 0; ctl_load(1) != j + 1 && w2 < (1 << 22); ++w2) __builtin_amdgcn_s_sleep(1);
-        const unsigned nb = ctl_load(0);
-        ctl_store(2, j + 1);
-        if (lane == 0)
-          __hip_atomic_exchange(sCur, (unsigned long long)nb << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // The request for the chunk after next is a returning global atomic.  As a builtin it makes
-        // hipcc give up counted vmcnt in the tile loop (loads and returning atomics may complete
-        // out of order); as inline asm with its own wait it is invisible to that pass, and an
-        // uncounted operation in flight only makes the compiler's counted waits wait for one load
-        // more, never fewer.  Executed once per 16 tiles.
-        unsigned g = 0;
-        if (lane == 0 && nb < nt) {
-          const unsigned zero = 0, inc = CH;
-          asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)"
-                       : "=&v"(g)
-                       : "v"(zero), "v"(inc), "s"(sched)
-                       : "memory");
-        }
-        g = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
-        ctl_store(0, nb < nt ? (unsigned)G * CH + g : nb);  // past the end: stay there
-        ctl_store(1, j + 2);
-      } else {
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    return nt;  // unreachable short of a scheduler fault; never hang the GPU
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(sNext, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    const unsigned t = blockIdx.x + k * G;  // k < rounds: no overflow (nt < 2^31, G <= num_cus)
+    return k < rounds && t < nt ? t : nt;
   };
 
   // loads tile tt; past the end it re-reads the workgroup's first tile (an L2 hit, result
   // unused): a branch around the prefetch would make hipcc's s_waitcnt placement assume the
   // no-prefetch path and wait for the prefetched loads at the head of every tile.
   auto load_tile = [&](unsigned tt, v2d(&a)[NB][2]) {
-    const long t = tt < nt ? tt : blockIdx.x * CH;
+    const long t = tt < nt ? tt : blockIdx.x;
     const char *base = reinterpret_cast<const char *>(X) + t * tile_bytes;  // scalar
     const unsigned off = t == last ? lane_off_last : lane_off;
 #pragma unroll
@@ -228,6 +227,7 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
 #pragma unroll
     for (int f = 0; f < NFRAG; ++f) wreg[f] = frags[f * 64 + lane];
   }
+  __syncthreads();
   // (!WREG) the factor fragments are loop-invariant LDS reads; left alone, hipcc hoists all of
   // them out of the tile loop into spilled registers.  An opaque per-tile lane offset keeps them
   // as in-loop ds_read_b64.
@@ -308,18 +308,18 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
       q += __shfl_xor(q, 32);
     }
     // lanes 0..15: particles 0..15 of the tile, one 128-byte line
-    if (lane < (t == last ? (int)tail_rows : 16)) out[t * 16 + lane] = finish(q, ep);
+    if (lane < (t == last ? (int)tail_rows : 16)) out[t * 16 + lane] = LOGMVN ? ep.lognorm - 0.5 * q : finish(q, ep);
   };
 
   // ABL == 4 (diagnostic build only): shader-clock and 100 MHz wall stamps per wave, written past
   // the end of `out`, never mixed into an output value.
   unsigned long long stamp_c = 0, stamp_r = 0;
-  if (ABL == 4 || ABL == 5) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
+  if (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   int done = 0;
 
   unsigned k0 = grab();
   if (k0 < nt) {
-    if constexpr (NB <= 4) {
+    if constexpr (mfma_sets<NB, SHIFT>() == 3) {
       // Three register sets in rotation: while one tile runs on the matrix cores the loads of
       // the next TWO are in flight (16 KB per wave).  No register copies: the loop is unrolled
       // by three with the roles renamed.
@@ -329,48 +329,43 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
       load_tile(k1, a1);
       while (true) {
         const unsigned k2 = grab();
-        if (ABL != 1 && ABL != 5) load_tile(k2, a2);
+        if (!NOLOAD) load_tile(k2, a2);
         compute_tile(k0, a0); ++done;
         if (k1 >= nt) break;
         k0 = grab();
-        if (ABL != 1 && ABL != 5) load_tile(k0, a0);
-        compute_tile(k1, (ABL == 1 || ABL == 5) ? a0 : a1); ++done;
+        if (!NOLOAD) load_tile(k0, a0);
+        compute_tile(k1, NOLOAD ? a0 : a1); ++done;
         if (k2 >= nt) break;
         k1 = grab();
-        if (ABL != 1 && ABL != 5) load_tile(k1, a1);
-        compute_tile(k2, (ABL == 1 || ABL == 5) ? a0 : a2); ++done;
+        if (!NOLOAD) load_tile(k1, a1);
+        compute_tile(k2, NOLOAD ? a0 : a2); ++done;
         if (k0 >= nt) break;
       }
-    } else {  // d >= 96: two sets (three would not fit the register file)
+    } else {  // two sets in rotation
       v2d a0[NB][2], a1[NB][2];
       load_tile(k0, a0);
       while (true) {
         const unsigned k1 = grab();
-        load_tile(k1, a1);
-        compute_tile(k0, a0);
+        if (!NOLOAD) load_tile(k1, a1);
+        compute_tile(k0, a0); ++done;
         if (k1 >= nt) break;
         k0 = grab();
-        load_tile(k0, a0);
-        compute_tile(k1, a1);
+        if (!NOLOAD) load_tile(k0, a0);
+        compute_tile(k1, NOLOAD ? a0 : a1); ++done;
         if (k0 >= nt) break;
       }
     }
   }
-  // the last workgroup out re-arms the scheduler for the next launch
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned dn = __hip_atomic_fetch_add(&sched[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (dn == (unsigned)G - 1) {
-      __hip_atomic_store(&sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&sched[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  if ((ABL == 4 || ABL == 5) && lane == 0) {
+  if (STAMP && lane == 0) {
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out + num_tiles * 16);
     const long wid = (long)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
     dbg[3 * wid] = __builtin_amdgcn_s_memtime() - stamp_c;
     dbg[3 * wid + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r;
     dbg[3 * wid + 2] = (unsigned long long)done;
+    unsigned long long *abs_t = dbg + 3 * (long)gridDim.x * (THREADS / 64);  // absolute 100 MHz stamps
+    abs_t[3 * wid] = stamp_entry;
+    abs_t[3 * wid + 1] = stamp_r;
+    abs_t[3 * wid + 2] = __builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -30,12 +30,11 @@ bool mfma_supported(int d, const void *X, int64_t ldx);
 // Host-side packing of M (d x d row-major) into the fragment order.
 void mfma_pack_frags(const double *M, int d, bool tri, double *frags);
 // tri: centred form (shift, no bias); !tri: affine form (bias, no shift).  has_shift = false
-// promises the shift vector is all zeros.  sched: two device words, zero before the first launch
-// (the kernel re-arms them itself); launches sharing them must be stream-ordered.
+// promises the shift vector is all zeros.
 hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool tri,
                               bool has_shift, const double *frags, const double *shift,
-                              const double *bias, const Epilogue &ep, double *out, unsigned *sched,
-                              int num_cus, hipStream_t stream);
+                              const double *bias, const Epilogue &ep, double *out, int num_cus,
+                              hipStream_t stream);
 
 // --- kernels/logpdf_mfma_wide.hip : d in {128, 192, 256}, output blocks split over 4 waves ------
 bool mfma_wide_supported(int d, const void *X, int64_t ldx);
