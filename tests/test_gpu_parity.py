@@ -195,6 +195,64 @@ def test_full_size_properties(cs, oracle, N, d):
     D.close(); D0.close()
 
 
+@pytest.mark.parametrize("d,N", [(64, 1), (64, 15), (64, 16), (64, 17), (64, 256 * 16 - 1), (64, 256 * 16), (64, 256 * 16 + 1),
+                                 (64, 3 * 256 * 16 - 5), (64, 8 * 256 * 16 + 7), (32, 256 * 16 * 2 + 33), (16, 70_001),
+                                 (48, 12_289), (96, 256 * 16 + 9)])
+@pytest.mark.parametrize("dist", ["mvn", "mvt"])
+def test_tile_deal_boundaries(cs, oracle, d, N, dist):
+    """Every particle is evaluated exactly once whatever N is relative to the deal (16-particle
+    tiles, one workgroup per CU, rounds of G tiles): ALL outputs against the hoisted-factor oracle,
+    on a buffer pre-filled with NaN and guarded by a sentinel past the end."""
+    import torch
+    rng = np.random.default_rng(N + d)
+    sigma, mu = spd(rng, d), rng.standard_normal(d)
+    Xh = mu + rng.standard_normal((N, d))
+    X = torch.from_numpy(Xh).cuda()
+    out = torch.full((N + 64,), float("nan"), dtype=torch.float64, device="cuda")
+    D = (cs.MultiVariateNormalDistribution(mu, sigma) if dist == "mvn"
+         else cs.MultiVariateTStudentDistribution(mu, sigma, 4.0))
+    D.ctx.use_torch_stream()
+    D.pdf_dev(X, out[:N])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.all(np.isnan(got[N:])), "wrote past the end of the output"
+    want = oracle.logpdf_hoisted(Xh, mu, sigma, None, dist, 4.0)
+    assert rel_err(got[:N], want) < RTOL
+    D.close()
+
+
+def test_full_size_properties_student_t(cs, oracle):
+    """BASELINE configs[3] shape (nu = 4, 1e6 x d = 64) through the same size-independent properties."""
+    import torch
+    N, d, nu = 1_000_000, 64, 4.0
+    g = torch.Generator(device="cuda").manual_seed(9)
+    X = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+    rng = np.random.default_rng(3)
+    sigma, mu = spd(rng, d), rng.standard_normal(d)
+    D = cs.MultiVariateTStudentDistribution(mu, sigma, nu)
+    D.ctx.use_torch_stream()
+    out = torch.empty(N, dtype=torch.float64, device="cuda")
+    D.pdf_dev(X, out)
+    torch.cuda.synchronize()
+    idx = torch.randint(0, N, (4096,), device="cuda", generator=g)
+    want = oracle.logpdf_hoisted(X[idx].cpu().numpy(), mu, sigma, None, "mvt", nu)
+    assert rel_err(out[idx].cpu().numpy(), want) < RTOL
+    perm = torch.randperm(N, device="cuda", generator=g)
+    out2 = torch.empty_like(out)
+    D.pdf_dev(X[perm].contiguous(), out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out[perm])
+    # the Student-t and the Normal density share q: logp_t = c_t - (nu+d)/2 log1p(q/nu), q = -2 (logp_n - c_n)
+    Dn = cs.MultiVariateNormalDistribution(mu, sigma)
+    outn = torch.empty_like(out)
+    Dn.pdf_dev(X, outn)
+    torch.cuda.synchronize()
+    q = -2.0 * (outn - Dn.lognorm())
+    back = D.lognorm() - 0.5 * (nu + d) * torch.log1p(q / nu)
+    assert float(((back - out).abs() / out.abs()).max()) < 1e-12
+    D.close(); Dn.close()
+
+
 # --- resampler: bit-exact index sequences -----------------------------------------------------------
 
 @pytest.mark.parametrize("name", RESAMPLE_CASES)
