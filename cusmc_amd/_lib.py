@@ -43,6 +43,8 @@ SYMBOLS = [
     ("cusmc_initialize_dev", _i, [_vp, _i, _f, _vp, _vp, _i, _d, _u64, _u32, _u32, _vp]),
     ("cusmc_sample_host", _i, [_vp, _i, _f, _vp, _vp, _i, _d, _u64, _u32, _u32, _vp]),
     ("cusmc_eigen_sqrt", _i, [_vp, _i, _vp]),
+    ("cusmc_pf_step_dev", _i, [_vp, _i, _f, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _d, _u64, _u32, _u32,
+                               _u32, _vp, _vp, _vp, _i]),
     ("cusmc_pf_run_host", _i, [_vp, _vp, _u32, _i, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _f,
                                C.c_char_p, C.c_char_p, _u32, _d, _u64, _vp, _vp, _vp]),
 ]

@@ -302,6 +302,23 @@ def propagate_dev(X_prev, a, G, Q, X_out, kind="mvn", nu=0.0, scale=1.0, seed=0,
     return X_out
 
 
+def pf_step_dev(obs, w_prev, X_prev, G, Q, y, F, a_out, X_out, w_out, kind="mvn", nu=0.0, B=10, scale=1.0,
+                seed=0, step=1, first=0, log=False):
+    """One time step of MCMC()'s loop (src/mcmc.cpp:292-308) on device-resident tensors:
+    resample over w_prev -> propagate -> reweight against the observation distribution `obs`
+    (pdf_{0,V}: its own mu is not used), for the rows [first, first + len(a_out)).  One launch for
+    d <= 8, the three separate kernels otherwise; same numbers either way."""
+    G, Q, y = _f64(G), _f64(Q), _f64(y).reshape(-1)
+    Fm = None if F is None else _f64(F)
+    check(_lib.lib().cusmc_pf_step_dev(obs._h, _MVT if kind == "mvt" else _MVN, C.c_float(nu),
+                                       C.c_void_p(w_prev.data_ptr()), C.c_void_p(X_prev.data_ptr()),
+                                       X_prev.shape[0], _ptr(G), _ptr(Q), _ptr(y), _ptr(Fm), int(B), float(scale),
+                                       int(seed), int(step), int(first), a_out.numel(),
+                                       C.c_void_p(a_out.data_ptr()), C.c_void_p(X_out.data_ptr()),
+                                       C.c_void_p(w_out.data_ptr()), OUT_LOG if log else OUT_DENSITY))
+    return a_out, X_out, w_out
+
+
 def initialize_dev(m0, Q, X_out, kind="mvn", nu=0.0, scale=1.0, seed=0, first=0, ctx=None):
     """initialize() draws on a device-resident tensor (src/mcmc.cpp:44-88)."""
     ctx = ctx or default_context()

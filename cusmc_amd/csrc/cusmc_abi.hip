@@ -623,6 +623,49 @@ CUSMC_EXPORT int cusmc_eigen_sqrt(const double *sigma, int d, double *Q)
   return CUSMC_OK;
 }
 
+// ---- one filter time step -------------------------------------------------------------------
+
+CUSMC_EXPORT int cusmc_pf_step_dev(cusmc_dist *obs, int kind, float nu, const double *w_prev_dev,
+                                   const double *X_prev_dev, uint32_t N, const double *G,
+                                   const double *Q, const double *y, const double *F, uint32_t B,
+                                   double scale, uint64_t seed, uint32_t step, uint32_t first,
+                                   uint32_t count, uint32_t *a_out_dev, double *X_out_dev,
+                                   double *w_out_dev, int flags)
+{
+  if (!obs) return fail(CUSMC_EINVAL, "null observation distribution");
+  cusmc_ctx *ctx = obs->ctx;
+  if (int rc = activate(ctx)) return rc;
+  if (kind != CUSMC_MVN && kind != CUSMC_MVT) return fail(CUSMC_EINVAL, "unknown distribution kind %d", kind);
+  if (kind == CUSMC_MVT && !(nu > 0.f)) return fail(CUSMC_EINVAL, "nu = %g must be positive", (double)nu);
+  if (!G || !Q || !y) return fail(CUSMC_EINVAL, "null G, Q or y");
+  if (N == 0) return fail(CUSMC_EINVAL, "N = 0");
+  if ((uint64_t)first + count > N) return fail(CUSMC_EINVAL, "shard [%u, %u) exceeds N = %u", first, first + count, N);
+  if (count == 0) return CUSMC_OK;
+  if (!w_prev_dev || !X_prev_dev || !a_out_dev || !X_out_dev || !w_out_dev)
+    return fail(CUSMC_EINVAL, "null device pointer");
+  const int d = obs->d;
+  if (!cusmc::pf_step_supported(d)) {
+    if (int rc = cusmc_metropolis_dev(ctx, w_prev_dev, N, B, seed, step, first, count, a_out_dev)) return rc;
+    if (int rc = draws(ctx, kind, nu, X_prev_dev, a_out_dev, G, Q, nullptr, d, scale, seed, step, 2u, first, count,
+                       X_out_dev))
+      return rc;
+    return cusmc_dist_reweight_dev(obs, X_out_dev, count, d, y, F, flags, w_out_dev);
+  }
+  if (int rc = plan_affine(obs, y, F)) return rc;
+  if (int rc = ensure_M(obs)) return rc;
+  const size_t dd = (size_t)d * d;
+  // device image [Q | G]: the small matrices are read through wave-uniform (scalar) loads
+  if (int rc = ctx->scratch[4].reserve(2 * dd * 8)) return rc;
+  if (int rc = upload_small(ctx, ctx->scratch[4], 0, Q, dd)) return rc;
+  if (int rc = upload_small(ctx, ctx->scratch[4], dd, G, dd)) return rc;
+  const double *base = (const double *)ctx->scratch[4].p;
+  HIP_TRY(cusmc::launch_pf_step(kind, nu, w_prev_dev, X_prev_dev, N, d, B, base + dd, base, scale, obs->plan_tri,
+                                (const double *)obs->Mdev.p, (const double *)obs->shift.p,
+                                (const double *)obs->bias.p, make_epilogue(obs, flags), seed, step, first,
+                                count, a_out_dev, X_out_dev, w_out_dev, ctx->num_cus, ctx->stream));
+  return CUSMC_OK;
+}
+
 // ---- the filter -----------------------------------------------------------------------------
 
 CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T,
@@ -678,11 +721,9 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   }
   // MCMC(): for t = 1..T-1: resample -> propagate -> reweight   src/mcmc.cpp:292-308
   for (uint32_t t = 1; t < T; ++t) {
-    rc = cusmc_metropolis_dev(ctx, w + (size_t)(t - 1) * N, N, B, seed, t, 0, N, a + (size_t)t * N);
-    if (!rc) rc = cusmc_propagate_dev(ctx, kind, df, X + (size_t)(t - 1) * slice, a + (size_t)t * N, N, d, G,
-                                      Qw.data(), scale, seed, t, 0, N, X + (size_t)t * slice);
-    if (!rc) rc = cusmc_dist_reweight_dev(obs, X + (size_t)t * slice, N, d, Y + (size_t)t * d, F,
-                                          CUSMC_OUT_DENSITY, w + (size_t)t * N);
+    rc = cusmc_pf_step_dev(obs, kind, df, w + (size_t)(t - 1) * N, X + (size_t)(t - 1) * slice, N, G, Qw.data(),
+                           Y + (size_t)t * d, F, B, scale, seed, t, 0, N, a + (size_t)t * N,
+                           X + (size_t)t * slice, w + (size_t)t * N, CUSMC_OUT_DENSITY);
     if (rc) return cleanup(rc);
   }
   hipError_t e = hipSuccess;

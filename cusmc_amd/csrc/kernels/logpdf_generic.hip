@@ -16,17 +16,9 @@
 // fallback for large odd d, not the tuned path.
 #include <hip/hip_runtime.h>
 
-#include "../launch.h"
-#include "../../../include/cusmc_hip.h"
+#include "smallops.h"
 
 namespace cusmc {
-
-static __device__ __forceinline__ double finish_generic(double q, const Epilogue &ep)
-{
-  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p(q * ep.inv_nu)
-                                     : ep.lognorm - 0.5 * q;
-  return ep.out_density ? exp(lp) : lp;
-}
 
 template <int T>
 __global__ __launch_bounds__(T) void logpdf_generic_kernel(

@@ -22,50 +22,9 @@
 // particle); DESIGN.md lists the MFMA formulation as the next step for d >= 32.
 #include <hip/hip_runtime.h>
 
-#include "../launch.h"
-#include "../philox.h"
-#include "../../../include/cusmc_hip.h"
+#include "smallops.h"
 
 namespace cusmc {
-
-static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, double &z1)
-{
-  const double u1 = 1.0 - u01_53(r.x, r.y);  // (0,1]
-  const double u2 = u01_53(r.z, r.w);        // [0,1)
-  const double rad = sqrt(-2.0 * log(u1));
-  const double ang = 2.0 * 3.14159265358979323846 * u2;
-  z0 = rad * cos(ang);
-  z1 = rad * sin(ang);
-}
-
-// chi^2_nu = 2 Gamma(nu/2, 1); counter layout as oracle/cusmc_oracle.c:chi_square_for.
-static __device__ double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, uint32_t k0,
-                                        uint32_t k1, float nu)
-{
-  double a = 0.5 * (double)nu;
-  double boost = 1.0;
-  if (a < 1.0) {
-    const u32x4 r = philox4x32_10(particle, j * 64u + 63u, step, 5u, k0, k1);
-    boost = pow(1.0 - u01_53(r.x, r.y), 1.0 / a);
-    a += 1.0;
-  }
-  const double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
-  double g = dd;
-  for (uint32_t m = 0; m < 63u; ++m) {
-    double z0, z1;
-    normal_pair(philox4x32_10(particle, j * 64u + m, step, 3u, k0, k1), z0, z1);
-    double v = 1.0 + c * z0;
-    if (v <= 0.0) continue;
-    v = v * v * v;
-    const u32x4 r = philox4x32_10(particle, j * 64u + m, step, 5u, k0, k1);
-    const double u = 1.0 - u01_53(r.x, r.y);
-    if (log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) {
-      g = dd * v;
-      break;
-    }
-  }
-  return 2.0 * g * boost;
-}
 
 template <int T>
 __global__ __launch_bounds__(T) void propagate_kernel(

@@ -11,13 +11,11 @@
 //
 // Cost model: per step one Philox4x32-10 block (~70 integer VALU ops), one 8-byte
 // random gather of w[j] -- w is 0.8 MB (N = 1e5, L2-resident) or 8 MB (N = 1e6,
-// Infinity-Cache-resident) -- and one fp64 divide.  The random numbers and the gather of step n
-// do not depend on the chain state, only the compare does, so the loop is unrolled by four:
-// four Philox blocks and four gathers are in flight before the four dependent accept tests.
+// Infinity-Cache-resident) -- and one fp64 divide.  The chain itself is metropolis_chain()
+// in smallops.h (shared with the fused filter step).
 #include <hip/hip_runtime.h>
 
-#include "../launch.h"
-#include "../philox.h"
+#include "smallops.h"
 
 namespace cusmc {
 
@@ -28,39 +26,7 @@ __global__ __launch_bounds__(256) void metropolis_kernel(const double *__restric
 {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
-    const uint32_t i = first + t;
-    uint32_t k = i;
-    double wk = w[i];
-    uint32_t n = 0;
-    for (; n + 4 <= B; n += 4) {
-      double u[4], wj[4];
-      uint32_t j[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const u32x4 r = philox4x32_10(i, n + c, step, 1u, k0, k1);
-        u[c] = u01_53(r.x, r.y);
-        j[c] = uint_below(r.z, r.w, N);
-        wj[c] = w[j[c]];
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (u[c] <= wj[c] / wk) {
-          k = j[c];
-          wk = wj[c];
-        }
-      }
-    }
-    for (; n < B; ++n) {
-      const u32x4 r = philox4x32_10(i, n, step, 1u, k0, k1);
-      const double u = u01_53(r.x, r.y);
-      const uint32_t j = uint_below(r.z, r.w, N);
-      const double wj = w[j];
-      if (u <= wj / wk) {
-        k = j;
-        wk = wj;
-      }
-    }
-    a[t] = k;
+    a[t] = metropolis_chain(w, N, B, first + t, step, k0, k1);
   }
 }
 

@@ -74,4 +74,13 @@ hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const
                                  uint32_t first, uint32_t count, double *X_out, int num_cus,
                                  hipStream_t stream);
 
+// --- kernels/pf_step.hip : resample + propagate + reweight in one launch, d <= 8 -----------------
+bool pf_step_supported(int d);
+hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const double *X_prev,
+                          uint32_t N, int d, uint32_t B, const double *G, const double *Q,
+                          double scale, bool tri, const double *M, const double *shift,
+                          const double *bias, const Epilogue &ep, uint64_t seed, uint32_t step,
+                          uint32_t first, uint32_t count, uint32_t *a_out, double *X_out,
+                          double *w_out, int num_cus, hipStream_t stream);
+
 }  // namespace cusmc

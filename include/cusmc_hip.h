@@ -149,6 +149,21 @@ int cusmc_sample_host(cusmc_ctx *ctx, int kind, float nu, const double *mu, cons
 /* eigenSolver -- src/linear_algebra.cpp:10-23:  Q = V sqrt(Lambda), Q Q^T = sigma.  Host only. */
 int cusmc_eigen_sqrt(const double *sigma, int d, double *Q);
 
+/* ---- one filter time step: the body of MCMC()'s loop -- src/mcmc.cpp:292-308 -----------------
+ *     a[i]   = Metropolis chain i over w_prev                 (cusmc_metropolis_dev)
+ *     x_t[i] = [diag(c_i)] Q (scale * xi_i) + G x_prev[a[i]]  (cusmc_propagate_dev, kind/nu of the proposal)
+ *     w_t[i] = pdf_{0,Sigma_obs}( y - F x_t[i] )              (cusmc_dist_reweight_dev on `obs`)
+ * for i in [first, first+count).  w_prev and X_prev hold all N particles of step t-1; the three
+ * outputs hold this caller's `count` rows.  For d <= 8 this is ONE launch (the state never leaves
+ * registers between the proposal and the weight); otherwise it is the three calls above, with
+ * identical results either way.  flags: CUSMC_OUT_LOG or CUSMC_OUT_DENSITY (what reweight_G
+ * stores, mcmc.cpp:208). */
+int cusmc_pf_step_dev(cusmc_dist *obs, int kind, float nu, const double *w_prev_dev,
+                      const double *X_prev_dev, uint32_t N, const double *G, const double *Q,
+                      const double *y, const double *F, uint32_t B, double scale, uint64_t seed,
+                      uint32_t step, uint32_t first, uint32_t count, uint32_t *a_out_dev,
+                      double *X_out_dev, double *w_out_dev, int flags);
+
 /* ---- the filter: particle_filter() -- src/particle_filter.cpp:6-39, MCMC() mcmc.cpp:239-309 -
  * Device-resident time loop: initialize, then for t = 1..T-1: resample(w_{t-1}) -> propagate
  * -> reweight.  Y is T x d (row t = y_t; the reference stores Y.col(t): run.rcpp.cpp:91).

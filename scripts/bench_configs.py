@@ -81,6 +81,32 @@ def main():
         t = timed(f, 10, 2)
         rows.append((name, "%.3g particles/s" % (N / t), "%.1f us" % (t * 1e6), "%.2f TB/s" % (N * (16 * d + 4) / t / 1e12), "-"))
         del Xp, anc, out
+    # one filter time step (resample + propagate + reweight), device-resident: fused launch vs three
+    for name, N, d in (("C3 filter step N=1e6 d=2 B=10", 1_000_000, 2), ("filter step N=1e6 d=8 B=10", 1_000_000, 8)):
+        I = np.eye(d)
+        Xp = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+        wp = torch.rand(N, dtype=torch.float64, device="cuda", generator=g)
+        a = torch.empty(N, dtype=torch.int32, device="cuda")
+        Xo = torch.empty(N, d, dtype=torch.float64, device="cuda")
+        wo = torch.empty(N, dtype=torch.float64, device="cuda")
+        obs = cusmc_amd.MultiVariateNormalDistribution(None, 0.5 * I, ctx=ctx)
+        y = np.zeros(d)
+        st = [0]
+
+        def fused():
+            st[0] += 1
+            cusmc_amd.api.pf_step_dev(obs, wp, Xp, I, 0.3 * I, y, I, a, Xo, wo, B=10, seed=1, step=st[0])
+
+        def three():
+            st[0] += 1
+            cusmc_amd.Sampler.metropolis_hastings_dev(wp, a, B=10, t=st[0], seed=1, ctx=ctx)
+            cusmc_amd.api.propagate_dev(Xp, a, I, 0.3 * I, Xo, "mvn", 0.0, 1.0, seed=1, step=st[0], ctx=ctx)
+            obs.reweight_dev(Xo, y, I, wo, log=False)
+        tf, t3 = timed(fused, 50, 5), timed(three, 50, 5)
+        rows.append((name, "%.3g particle-steps/s" % (N / tf), "%.1f us fused (%.1f us as three launches)" % (tf * 1e6, t3 * 1e6),
+                     "%.2f TB/s" % (N * (16 * d + 12) / tf / 1e12), "-"))
+        obs.close()
+        del Xp, wp, a, Xo, wo
     # filter (host round trip included: that is what run() does)
     for name, N, d, T in (("C3 run() N=1e6 d=2 T=100", 1_000_000, 2, 100), ("run() N=2e5 d=64 T=10", 200_000, 64, 10)):
         I = np.eye(d)

@@ -405,6 +405,44 @@ def test_filter_against_oracle_larger(cs, oracle):
     assert np.allclose(out["weights"][:, ok], w[:, ok], rtol=1e-6)
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16])
+@pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0)])
+@pytest.mark.parametrize("general_F", [False, True])
+def test_fused_step_equals_three_launches(cs, d, dist, nu, general_F):
+    """cusmc_pf_step_dev (one launch for d <= 8) against resample -> propagate -> reweight through
+    the separate entry points: ancestors identical, states and weights bitwise identical; also on
+    a shard [first, first + count) of the chains."""
+    import torch
+    from cusmc_amd import api
+    N, B, seed, step = 20_011, 10, 77, 3
+    rng = np.random.default_rng(d + 10 * general_F)
+    g = torch.Generator(device="cuda").manual_seed(d)
+    Xp = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+    wp = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 1e-12
+    G = 0.9 * np.eye(d) + 0.05 * rng.standard_normal((d, d))
+    Q = 0.3 * np.eye(d) + 0.02 * rng.standard_normal((d, d))
+    F = np.eye(d) + (0.1 * rng.standard_normal((d, d)) if general_F else 0.0)
+    y = rng.standard_normal(d)
+    V = spd(rng, d)
+    obs = (cs.MultiVariateNormalDistribution(None, V) if dist == "mvn"
+           else cs.MultiVariateTStudentDistribution(None, V, nu))
+    obs.ctx.use_torch_stream()
+    for first, count in ((0, N), (5_003, 9_999)):
+        a1 = torch.empty(count, dtype=torch.int32, device="cuda")
+        X1 = torch.empty(count, d, dtype=torch.float64, device="cuda")
+        w1 = torch.empty(count, dtype=torch.float64, device="cuda")
+        api.pf_step_dev(obs, wp, Xp, G, Q, y, F, a1, X1, w1, kind=dist, nu=nu, B=B, seed=seed, step=step, first=first)
+        a2 = torch.empty_like(a1); X2 = torch.empty_like(X1); w2 = torch.empty_like(w1)
+        cs.Sampler.metropolis_hastings_dev(wp, a2, B=B, t=step, seed=seed, first=first, ctx=obs.ctx)
+        api.propagate_dev(Xp, a2, G, Q, X2, dist, nu, 1.0, seed=seed, step=step, first=first, ctx=obs.ctx)
+        obs.reweight_dev(X2, y, F, w2, log=False)
+        torch.cuda.synchronize()
+        assert torch.equal(a1, a2)
+        assert torch.equal(X1, X2)
+        assert torch.equal(w1, w2)
+    obs.close()
+
+
 def test_filter_rejects_unknown_options(cs):
     I = np.eye(2)
     Y = np.zeros((2, 3))
