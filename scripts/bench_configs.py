@@ -46,7 +46,7 @@ def main():
         out = torch.empty(N, dtype=torch.float64, device="cuda")
         D = (cusmc_amd.MultiVariateNormalDistribution(np.zeros(d), spd(d, 1), ctx=ctx) if dist == "mvn"
              else cusmc_amd.MultiVariateTStudentDistribution(np.zeros(d), spd(d, 1), nu, ctx=ctx))
-        t = timed(lambda: D.pdf_dev(X, out), 200 if N * d <= 7e7 else 60, 30)
+        t = timed(lambda: D.pdf_dev(X, out), 400 if N * d <= 7e7 else 100, 400)  # (clock governor: ~50 ms to settle)
         nb = d // 16
         flops = N / 16 * 2 * nb * (nb + 1) * 2048 if d % 16 == 0 else N * (d * d + 4 * d)
         rows.append((name, "%.3g evals/s" % (N / t), "%.1f us" % (t * 1e6), "%.2f TB/s" % (N * (8 * d + 8) / t / 1e12),
