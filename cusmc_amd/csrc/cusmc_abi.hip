@@ -548,6 +548,22 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
   if (count == 0) return CUSMC_OK;
   if (!X_out_dev) return fail(CUSMC_EINVAL, "null output pointer");
   const size_t dd = (size_t)d * d;
+  if (cusmc::la::is_diagonal(Q, d) && (!G || cusmc::la::is_diagonal(G, d))) {
+    // device image: [diag(Q) | diag(G) | m0]
+    std::vector<double> img(3 * (size_t)d, 0.0);
+    for (int j = 0; j < d; ++j) {
+      img[j] = Q[(size_t)j * d + j];
+      if (G) img[d + j] = G[(size_t)j * d + j];
+      if (m0) img[2 * d + j] = m0[j];
+    }
+    if (int rc = ctx->scratch[4].reserve(img.size() * 8)) return rc;
+    if (int rc = ctx->ring.upload(ctx->scratch[4].p, img.data(), img.size() * 8, ctx->stream)) return rc;
+    const double *base = (const double *)ctx->scratch[4].p;
+    HIP_TRY(cusmc::launch_propagate_diag(kind, nu, X_prev_dev, a_dev, G ? base + d : nullptr, base,
+                                         m0 ? base + 2 * d : nullptr, d, scale, seed, step, domain, first, count,
+                                         X_out_dev, ctx->num_cus, ctx->stream));
+    return CUSMC_OK;
+  }
   if (cusmc::propagate_mfma_supported(d, X_prev_dev, X_out_dev)) {
     // device image: [frags(Q) | frags(G) | m0], fragments in the MFMA operand order
     const size_t nf = (size_t)cusmc::mfma_num_frags(d / 16, false) * 64;

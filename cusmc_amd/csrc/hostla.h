@@ -78,6 +78,14 @@ inline bool is_identity(const double *F, int n)
   return true;
 }
 
+inline bool is_diagonal(const double *A, int n)
+{
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      if (i != j && A[i * n + j] != 0.0) return false;
+  return true;
+}
+
 // Q = V sqrt(Lambda) from the symmetric eigen-decomposition (cyclic Jacobi), the matrix
 // eigenSolver() builds (src/linear_algebra.cpp:13-22).  Q Q^T = S; negative round-off
 // eigenvalues are clamped to zero.

@@ -24,9 +24,9 @@
 
 namespace cusmc {
 
-template <int D>
+template <int D, bool MVT>
 __global__ __launch_bounds__(256) void pf_step_kernel(
-    int kind, float nu, const double *__restrict__ w_prev, const double *__restrict__ X_prev,
+    float nu, const double *__restrict__ w_prev, const double *__restrict__ X_prev,
     uint32_t N, uint32_t B, const double *__restrict__ G, const double *__restrict__ Q,
     double scale, int tri, const double *__restrict__ M, const double *__restrict__ shift,
     const double *__restrict__ bias, Epilogue ep, uint32_t k0, uint32_t k1, uint32_t step,
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < D; ++k) s = fma(Q[j * D + k], xi[k], s);
-      if (kind == CUSMC_MVT) s *= sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu));
+      if (MVT) s = fma(s, sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu)), 0.0);  // (an fma, so that no kernel contracts it with the add below)
       double m = 0.0;
 #pragma unroll
       for (int k = 0; k < D; ++k) m = fma(G[j * D + k], xp[k], m);
@@ -103,12 +103,13 @@ hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const double
   const long cap = (long)num_cus * 8;
   if (blocks > cap) blocks = cap;
 #define CUSMC_PF(D)                                                                                \
-  case D:                                                                                          \
-    hipLaunchKernelGGL(pf_step_kernel<D>, dim3((unsigned)blocks), dim3(256), 0, stream, kind, nu,  \
-                       w_prev, X_prev, N, B, G, Q, scale, (int)tri, M, shift, bias, ep,            \
-                       (uint32_t)seed, (uint32_t)(seed >> 32), step, first, count, a_out, X_out,   \
-                       w_out);                                                                     \
-    break;
+  case D: {                                                                                        \
+    auto kern = kind == CUSMC_MVT ? pf_step_kernel<D, true> : pf_step_kernel<D, false>;            \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, nu, w_prev, X_prev, N,  \
+                       B, G, Q, scale, (int)tri, M, shift, bias, ep, (uint32_t)seed,               \
+                       (uint32_t)(seed >> 32), step, first, count, a_out, X_out, w_out);           \
+    break;                                                                                         \
+  }
   switch (d) {
     CUSMC_PF(1) CUSMC_PF(2) CUSMC_PF(3) CUSMC_PF(4) CUSMC_PF(5) CUSMC_PF(6) CUSMC_PF(7) CUSMC_PF(8)
     default: return hipErrorInvalidValue;

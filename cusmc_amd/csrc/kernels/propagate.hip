@@ -71,7 +71,7 @@ __global__ __launch_bounds__(T) void propagate_kernel(
         const double *Qj = Q + (long)j * d;
         double s = 0.0;
         for (int k = 0; k < d; ++k) s = fma(Qj[k], xi[k], s);
-        if (kind == CUSMC_MVT) s *= sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu));
+        if (kind == CUSMC_MVT) s = fma(s, sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu)), 0.0);  // (an fma, so that no kernel contracts it with the add below)
         double m;
         if (G) {
           const double *Gj = G + (long)j * d;
@@ -84,6 +84,67 @@ __global__ __launch_bounds__(T) void propagate_kernel(
       }
     }
   }
+}
+
+// Diagonal G and Q (random-walk and independent-component models: the reference's own
+// generateInput() uses G = I, W = 0.001 I, src/mcmc.cpp:22-23): the two mat-vecs collapse to one
+// multiply per component, so there is nothing to stage and nothing for the matrix cores -- one lane
+// per (particle, component pair), i.e. per Philox block, consecutive lanes on consecutive pairs of
+// one row (16-byte segments, fully coalesced), any d.  Same operations as the general kernels
+// (fma(q, xi, 0) is the only non-zero term of their sum), hence the same values.
+template <bool MVT>
+__global__ __launch_bounds__(256) void propagate_diag_kernel(
+    float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
+    const double *__restrict__ gdiag, const double *__restrict__ qdiag, const double *__restrict__ m0,
+    int d, int pw_log2, double scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t domain,
+    uint32_t first, uint32_t count, double *__restrict__ X_out)
+{
+  // 2^pw_log2 lanes per row (>= the number of pairs up to 256, no division anywhere); a block
+  // covers 256 >> pw_log2 rows per pass
+  const int pairs = (d + 1) / 2;
+  const int pw = 1 << pw_log2;
+  const int rows_per_block = 256 >> pw_log2;
+  const int lane_pr = (int)threadIdx.x & (pw - 1);
+  const uint32_t lane_row = threadIdx.x >> pw_log2;
+  for (uint32_t il = blockIdx.x * rows_per_block + lane_row; il < count; il += gridDim.x * rows_per_block) {
+    const uint32_t i = first + il;
+    const long anc = gdiag ? (a ? (long)a[il] : (long)i) : 0;
+    for (int pr = lane_pr; pr < pairs; pr += pw) {
+      double z[2];
+      normal_pair(philox4x32_10(i, (uint32_t)pr, step, domain, k0, k1), z[0], z[1]);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j = 2 * pr + c;
+        if (j < d) {
+          const double xi = scale * z[c];
+          double s = fma(qdiag[j], xi, 0.0);
+          if (MVT) s = fma(s, sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu)), 0.0);  // (an fma, so that no kernel contracts it with the add below)
+          const double m = gdiag ? fma(gdiag[j], X_prev[anc * d + j], 0.0) : m0[j];
+          X_out[(long)il * d + j] = s + m;
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const uint32_t *a,
+                                 const double *gdiag, const double *qdiag, const double *m0, int d,
+                                 double scale, uint64_t seed, uint32_t step, uint32_t domain,
+                                 uint32_t first, uint32_t count, double *X_out, int num_cus,
+                                 hipStream_t stream)
+{
+  if (count == 0) return hipSuccess;
+  const int pairs = (d + 1) / 2;
+  int pw_log2 = 0;
+  while ((1 << pw_log2) < pairs && pw_log2 < 8) ++pw_log2;
+  const long rows_per_block = 256 >> pw_log2;
+  long blocks = ((long)count + rows_per_block - 1) / rows_per_block;
+  const long cap = (long)num_cus * 8;
+  if (blocks > cap) blocks = cap;
+  auto kern = kind == CUSMC_MVT ? propagate_diag_kernel<true> : propagate_diag_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, nu, X_prev, a, gdiag, qdiag, m0, d,
+                     pw_log2, scale, (uint32_t)seed, (uint32_t)(seed >> 32), step, domain, first, count, X_out);
+  return hipGetLastError();
 }
 
 template <int T>

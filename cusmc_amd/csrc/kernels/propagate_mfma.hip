@@ -17,14 +17,10 @@
 //              Student-t proposal Q xi and G x keep separate accumulators because each component
 //              of Q xi is scaled by its own sqrt(nu / chi2) (src/statistics.cc.cpp:385-386, 411).
 // An f64 MFMA blocks VALU issue on its SIMD, so this kernel is VALU + MFMA
-// serialised: ~250 VALU instructions per Box-Muller pair dominate (8 pairs per lane per tile at
-// d = 64) -- it is RNG-bound, not HBM-bound.  Workgroup = 8 waves sharing the LDS factor image and
+// serialised: the Philox blocks and Box-Muller pairs (8 per lane per tile at d = 64; ln and
+// sincos(2 pi u) from smallops.h) weigh as much as the 128 MFMAs -- it is RNG-bound, not HBM-bound.  Workgroup = 8 waves sharing the LDS factor image and
 // an LDS tile counter.
-#include <hip/hip_runtime.h>
-
-#include "../launch.h"
-#include "../philox.h"
-#include "../../../include/cusmc_hip.h"
+#include "smallops.h"
 
 namespace cusmc {
 
@@ -35,12 +31,7 @@ __host__ __device__ constexpr int pm_pi(int s, int h) { return 2 * h + (s & 1) +
 
 static __device__ __forceinline__ void pm_normal_pair(const u32x4 r, double &z0, double &z1)
 {
-  const double u1 = 1.0 - u01_53(r.x, r.y);  // (0,1]
-  const double u2 = u01_53(r.z, r.w);        // [0,1)
-  const double rad = sqrt(-2.0 * log(u1));
-  const double ang = 2.0 * 3.14159265358979323846 * u2;
-  z0 = rad * cos(ang);
-  z1 = rad * sin(ang);
+  normal_pair(r, z0, z1);  // smallops.h: the same Box-Muller as every other draw path
 }
 
 // chi^2_nu = 2 Gamma(nu/2, 1); counter layout as oracle/cusmc_oracle.c:chi_square_for.
@@ -64,7 +55,7 @@ static __device__ __attribute__((noinline)) double pm_chi_square(uint32_t partic
     v = v * v * v;
     const u32x4 r = philox4x32_10(particle, j * 64u + m, step, 5u, k0, k1);
     const double u = 1.0 - u01_53(r.x, r.y);
-    if (log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) {
+    if (ln_pos(u) < 0.5 * z0 * z0 + dd - dd * v + dd * ln_pos(v)) {
       g = dd * v;
       break;
     }

@@ -10,15 +10,79 @@
 
 namespace cusmc {
 
-// Box-Muller on one Philox block: u1 in (0,1], u2 in [0,1).
+// ln(x) for finite x > 0, < 1 ulp: the classic reduction x = 2^e m, m in [sqrt(1/2), sqrt(2)),
+// ln(m) = 2 atanh(s), s = (m - 1) / (m + 1), with the degree-7 minimax polynomial in s^2 and the
+// hi/lo split of ln 2 of Sun's fdlibm e_log.c (constants from there).  The library log (ocml) costs
+// several hundred instructions here because it also serves denormals, infinities and negative
+// arguments; a uniform variate needs none of that, and every draw pays for it.
+static __device__ __forceinline__ double ln_pos(double x)
+{
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  if (m < 0.70710678118654752440) {
+    m *= 2.0;
+    e -= 1;
+  }
+  const double f = m - 1.0;
+  // s = f / (2 + f): reciprocal seed + two Newton steps + one residual correction (< 1 ulp)
+  const double den = 2.0 + f;
+  double r = __builtin_amdgcn_rcp(den);
+  r = r * fma(-den, r, 2.0);
+  r = r * fma(-den, r, 2.0);
+  double sq = f * r;
+  sq = fma(fma(-den, sq, f), r, sq);
+  const double z = sq * sq, w = z * z;
+  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+  const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)e;
+  return dk * ln2_hi - ((hfsq - (sq * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// cos(2 pi u), sin(2 pi u) for u in [0, 1): exact reduction to a quadrant (2u = q/2 + r,
+// |r| <= 1/4), then fdlibm's k_sin.c / k_cos.c kernels on x = pi r, |x| <= pi/4 (constants from
+// there).  No Payne-Hanek path, no double-double: < 1.5 ulp on both.
+static __device__ __forceinline__ void sincos_2pi(double u, double &c, double &s)
+{
+  const double t = 2.0 * u;                // [0, 2), exact
+  const double q = __builtin_rint(2.0 * t);  // 0..4
+  const double r = fma(-0.5, q, t);        // exact, |r| <= 1/4
+  const double pi_hi = 3.14159265358979311600e+00, pi_lo = 1.22464679914735317723e-16;
+  const double x = fma(r, pi_hi, r * pi_lo);
+  const double z = x * x;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double v = z * x;
+  const double ps = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+  const double sx = fma(v, fma(z, ps, S1), x);
+  const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+  const double hz = 0.5 * z;
+  const double w1 = 1.0 - hz;
+  const double cx = w1 + (((1.0 - w1) - hz) + z * pc);
+  const int qi = (int)q & 3;
+  const double a = (qi & 1) ? sx : cx;   // |cos| takes sx in odd quadrants
+  const double b = (qi & 1) ? cx : sx;
+  c = (qi == 1 || qi == 2) ? -a : a;
+  s = (qi >= 2) ? -b : b;
+}
+
+// Box-Muller on one Philox block: u1 in (0,1], u2 in [0,1):
+//     z0 = sqrt(-2 ln u1) cos(2 pi u2),  z1 = sqrt(-2 ln u1) sin(2 pi u2)
+// (oracle/cusmc_oracle.c evaluates the same expressions with libm; the two agree to a few ulp).
 static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, double &z1)
 {
   const double u1 = 1.0 - u01_53(r.x, r.y);  // (0,1]
   const double u2 = u01_53(r.z, r.w);        // [0,1)
-  const double rad = sqrt(-2.0 * log(u1));
-  const double ang = 2.0 * 3.14159265358979323846 * u2;
-  z0 = rad * cos(ang);
-  z1 = rad * sin(ang);
+  const double rad = sqrt(-2.0 * ln_pos(u1));
+  double c, s;
+  sincos_2pi(u2, c, s);
+  z0 = rad * c;
+  z1 = rad * s;
 }
 
 // chi^2_nu = 2 Gamma(nu/2, 1) by Marsaglia-Tsang (the reference's device sampler,
@@ -43,7 +107,7 @@ static __device__ double chi_square_for(uint32_t particle, uint32_t j, uint32_t 
     v = v * v * v;
     const u32x4 r = philox4x32_10(particle, j * 64u + m, step, 5u, k0, k1);
     const double u = 1.0 - u01_53(r.x, r.y);
-    if (log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) {
+    if (ln_pos(u) < 0.5 * z0 * z0 + dd - dd * v + dd * ln_pos(v)) {
       g = dd * v;
       break;
     }

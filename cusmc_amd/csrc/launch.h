@@ -74,6 +74,13 @@ hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const
                                  uint32_t first, uint32_t count, double *X_out, int num_cus,
                                  hipStream_t stream);
 
+// diagonal G (or none: m0) and diagonal Q, any d: one lane per component pair
+hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const uint32_t *a,
+                                 const double *gdiag, const double *qdiag, const double *m0, int d,
+                                 double scale, uint64_t seed, uint32_t step, uint32_t domain,
+                                 uint32_t first, uint32_t count, double *X_out, int num_cus,
+                                 hipStream_t stream);
+
 // --- kernels/pf_step.hip : resample + propagate + reweight in one launch, d <= 8 -----------------
 bool pf_step_supported(int d);
 hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const double *X_prev,

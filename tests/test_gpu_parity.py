@@ -366,6 +366,57 @@ def test_propagate_matches_oracle(cs, oracle, d, dist, nu):
     assert torch.equal(part, out[first:first + count])
 
 
+@pytest.mark.parametrize("d", [1, 2, 9, 16, 64, 70, 200])
+@pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0)])
+def test_propagate_diagonal_models(cs, oracle, d, dist, nu):
+    """Diagonal G and Q (random-walk / independent-component models, e.g. generateInput(),
+    src/mcmc.cpp:22-23) take the lane-per-component-pair kernel at any d: against the oracle,
+    which runs the dense loops, and shard-composable like the general kernels."""
+    import torch
+    rng = np.random.default_rng(d + 170)
+    N = 2000 + 3
+    Xp = rng.standard_normal((N, d))
+    a = rng.integers(0, N, N).astype(np.uint32)
+    G = np.diag(0.5 + rng.random(d))
+    Q = np.diag(0.1 + rng.random(d))
+    want = oracle.propagate(Xp, a, G, Q, dist, nu, 1.0, seed=78, step=4)
+    ctx = cs.api.default_context().use_torch_stream()
+    Xd = torch.from_numpy(Xp).cuda()
+    ad = torch.from_numpy(a.astype(np.int32)).cuda()
+    out = torch.full((N + 1, d), float("nan"), dtype=torch.float64, device="cuda")
+    cs.api.propagate_dev(Xd, ad, G, Q, out[:N], dist, nu, 1.0, seed=78, step=4, ctx=ctx)
+    torch.cuda.synchronize()
+    assert np.allclose(out[:N].cpu().numpy(), want, rtol=1e-9, atol=1e-9)
+    assert bool(torch.isnan(out[N]).all())
+    first, count = 777, 1001
+    part = torch.empty(count, d, dtype=torch.float64, device="cuda")
+    cs.api.propagate_dev(Xd, ad[first:first + count].contiguous(), G, Q, part, dist, nu, 1.0, seed=78, step=4,
+                         first=first, ctx=ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(part, out[first:first + count])
+    # initialize(): no G, m0 instead
+    m0 = rng.standard_normal(d)
+    want0, _ = oracle.initialize(N, m0, Q, dist, nu, 1.0, seed=78, step=0)
+    init = torch.empty(N, d, dtype=torch.float64, device="cuda")
+    cs.api.initialize_dev(m0, Q, init, dist, nu, 1.0, seed=78, ctx=ctx)
+    torch.cuda.synchronize()
+    assert np.allclose(init.cpu().numpy(), want0, rtol=1e-9, atol=1e-9)
+
+
+def test_box_muller_accuracy(cs, oracle):
+    """The device Box-Muller uses its own ln / sincos(2 pi u) (kernels/smallops.h), the oracle libm's.
+    With Q = I and mu = 0 a draw IS the normal variate: 2e5 of them agree to a few ulp of the largest
+    value (|z| <= 8.6), far inside the 1e-9 the draw tests allow -- and the sample moments are right."""
+    d, n = 2, 100_000
+    D = cs.MultiVariateNormalDistribution(np.zeros(d), np.eye(d))
+    got = D.sample(np.eye(d), 200, count=n, compat=False, seed=2024, step=9)
+    want, _ = oracle.initialize(n, np.zeros(d), np.eye(d), "mvn", 0.0, 1.0, seed=2024, step=9)
+    D.close()
+    assert np.max(np.abs(got - want)) < 2e-14
+    assert abs(got.mean()) < 0.01 and abs(got.var() - 1.0) < 0.01
+    assert abs(np.mean(got[:, 0] * got[:, 1])) < 0.01
+
+
 def test_R_level_draws(cs):
     x = cs.MVN([0.0, 0.0], np.eye(2))
     t = cs.MVT([0.0, 0.0, 0.0], np.eye(3), 3.0)
@@ -407,8 +458,8 @@ def test_filter_against_oracle_larger(cs, oracle):
 
 @pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0)])
-@pytest.mark.parametrize("general_F", [False, True])
-def test_fused_step_equals_three_launches(cs, d, dist, nu, general_F):
+@pytest.mark.parametrize("general_F,diag_model", [(False, False), (True, False), (False, True)])
+def test_fused_step_equals_three_launches(cs, d, dist, nu, general_F, diag_model):
     """cusmc_pf_step_dev (one launch for d <= 8) against resample -> propagate -> reweight through
     the separate entry points: ancestors identical, states and weights bitwise identical; also on
     a shard [first, first + count) of the chains."""
@@ -421,6 +472,8 @@ def test_fused_step_equals_three_launches(cs, d, dist, nu, general_F):
     wp = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 1e-12
     G = 0.9 * np.eye(d) + 0.05 * rng.standard_normal((d, d))
     Q = 0.3 * np.eye(d) + 0.02 * rng.standard_normal((d, d))
+    if diag_model:  # the separate propagate then takes the diagonal kernel: same values all the same
+        G, Q = np.diag(np.diag(G)), np.diag(np.diag(Q))
     F = np.eye(d) + (0.1 * rng.standard_normal((d, d)) if general_F else 0.0)
     y = rng.standard_normal(d)
     V = spd(rng, d)
