@@ -10,7 +10,7 @@ bool mfma_supported(int d, const void *X, int64_t ldx)
 {
   if (d % 16 != 0) return false;
   const int nb = d / 16;
-  if (!(nb == 1 || nb == 2 || nb == 3 || nb == 4 || nb == 6 || nb == 8)) return false;
+  if (nb < 1 || nb > 8) return false;
   // the A-operand loads are 16-byte vector loads
   // ... and a tile's per-lane byte offset is kept in 32 bits
   return ((uintptr_t)X % 16 == 0) && (ldx % 2 == 0) && (ldx < (1L << 24));
@@ -75,7 +75,9 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
     CUSMC_CASE(2)
     CUSMC_CASE(3)
     CUSMC_CASE(4)
+    CUSMC_CASE(5)
     CUSMC_CASE(6)
+    CUSMC_CASE(7)
     CUSMC_CASE(8)
   }
 #undef CUSMC_CASE

@@ -38,7 +38,7 @@ def main():
     ctx = cusmc_amd.api.default_context().use_torch_stream()
     g = torch.Generator(device="cuda").manual_seed(7)
     cells = []
-    for d in (16, 32, 48, 64, 96):
+    for d in (16, 32, 48, 64, 80, 96, 112):
         N = 64_000_000 // d
         X = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
         out = torch.empty(N, dtype=torch.float64, device="cuda")

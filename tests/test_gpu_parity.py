@@ -72,7 +72,7 @@ def test_pdf_against_golden(cs, golden, d, dist):
     D.close()
 
 
-@pytest.mark.parametrize("d", [2, 8, 16, 32, 48, 64, 96, 128, 192, 256])
+@pytest.mark.parametrize("d", [2, 8, 16, 32, 48, 64, 80, 96, 112, 128, 144, 192, 256])
 @pytest.mark.parametrize("dist", ["mvn", "mvt"])
 def test_pdf_against_oracle_seeded(cs, oracle, d, dist):
     """Same seeded inputs through the HIP path and the reference-faithful CPU restatement
@@ -89,7 +89,7 @@ def test_pdf_against_oracle_seeded(cs, oracle, d, dist):
     D.close()
 
 
-@pytest.mark.parametrize("d", [2, 16, 64, 128, 256])
+@pytest.mark.parametrize("d", [2, 16, 64, 80, 112, 128, 256])
 def test_reweight_general_F_against_oracle(cs, oracle, d):
     rng = np.random.default_rng(d)
     N = 500 if d <= 64 else 150
