@@ -181,7 +181,7 @@ int install_plan(cusmc_dist *dist, int plan, bool tri, const std::vector<double>
     if (F_key) dist->plan_F.assign(F_key, F_key + dd); else dist->plan_F.clear();
   }
   // shift / bias: padded to a multiple of 16 entries for the MFMA kernel's LDS image
-  const size_t padded = (size_t)((d + 15) / 16) * 16;
+  const size_t padded = (size_t)((d + 63) / 64) * 64;  // covers every kernel's 16*NB (the wide kernel runs d = 144 as 192)
   if (dist->plan_shift != shift || dist->shift.p == nullptr) {
     std::vector<double> tmp(padded, 0.0);
     std::copy(shift.begin(), shift.end(), tmp.begin());
@@ -202,14 +202,23 @@ int install_plan(cusmc_dist *dist, int plan, bool tri, const std::vector<double>
 int ensure_frags(cusmc_dist *dist, int kind)
 {
   if (dist->frags_valid && dist->frags_kind == kind) return CUSMC_OK;
-  const int d = dist->d, nb = d / 16;
+  const int d = dist->d, nb = kind == 2 ? cusmc::mfma_wide_nb(d) : (d + 15) / 16, dp = 16 * nb;
   const size_t n = kind == 2 ? cusmc::mfma_wide_frag_doubles(nb, dist->plan_tri)
                              : (size_t)cusmc::mfma_num_frags(nb, dist->plan_tri) * 64;
   std::vector<double> frags(n, 0.0);
+  // zero-pad M to 16*nb when d is not that already: the extra output rows give z = 0, the extra
+  // columns only ever meet zeros (the kernels mask what they load there)
+  std::vector<double> Mp;
+  const double *M = dist->hostM.data();
+  if (dp != d) {
+    Mp.assign((size_t)dp * dp, 0.0);
+    for (int i = 0; i < d; ++i) std::copy(dist->hostM.begin() + (size_t)i * d, dist->hostM.begin() + (size_t)(i + 1) * d, Mp.begin() + (size_t)i * dp);
+    M = Mp.data();
+  }
   if (kind == 2)
-    cusmc::mfma_wide_pack_frags(dist->hostM.data(), d, dist->plan_tri, frags.data());
+    cusmc::mfma_wide_pack_frags(M, dp, dist->plan_tri, frags.data());
   else
-    cusmc::mfma_pack_frags(dist->hostM.data(), d, dist->plan_tri, frags.data());
+    cusmc::mfma_pack_frags(M, dp, dist->plan_tri, frags.data());
   if (int rc = dist->frags.reserve(n * 8)) return rc;
   if (int rc = dist->ctx->ring.upload(dist->frags.p, frags.data(), n * 8, dist->ctx->stream)) return rc;
   dist->frags_valid = true;

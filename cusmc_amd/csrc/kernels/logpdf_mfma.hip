@@ -6,14 +6,17 @@ namespace cusmc {
 
 int mfma_num_frags(int nb, bool tri) { return tri ? 4 * nb * (nb + 1) / 2 : 4 * nb * nb; }
 
+// d = 16, 32, ..., 128 with 16-byte aligned rows take the plain kernel; every other d in (16, 128]
+// and every other alignment the padded variant (PAD).  d < 16 stays with the generic kernel: a
+// single, mostly empty k-block would cost more loads than it saves.  A tile's per-lane byte offset
+// is kept in 32 bits.
 bool mfma_supported(int d, const void *X, int64_t ldx)
 {
-  if (d % 16 != 0) return false;
-  const int nb = d / 16;
-  if (nb < 1 || nb > 8) return false;
-  // the A-operand loads are 16-byte vector loads
-  // ... and a tile's per-lane byte offset is kept in 32 bits
-  return ((uintptr_t)X % 16 == 0) && (ldx % 2 == 0) && (ldx < (1L << 24));
+  return d >= 16 && d <= 128 && ldx < (1L << 24);
+}
+static bool mfma_needs_pad(int d, const void *X, int64_t ldx)
+{
+  return d % 16 != 0 || (uintptr_t)X % 16 != 0 || ldx % 2 != 0;
 }
 
 // Fragment f (kernel loop order: kb, then s, then cb) holds, for lane l = (j, h):
@@ -31,8 +34,8 @@ void mfma_pack_frags(const double *M, int d, bool tri, double *frags)
         }
 }
 
-template <int NB, bool TRI, bool SHIFT, bool LOGMVN>
-static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, const double *frags,
+template <int NB, bool TRI, bool SHIFT, bool LOGMVN, bool PAD>
+static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, int d, const double *frags,
                             const double *shift, const double *bias, const Epilogue &ep,
                             double *out, int num_cus, hipStream_t stream)
 {
@@ -41,7 +44,7 @@ static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, const doubl
   constexpr int THREADS = mfma_threads<NB>();
   const size_t lds_bytes = (size_t)(32 * NB + 4 + (WREG ? 0 : NFRAG * 64)) * sizeof(double);
   const long num_tiles = (N + 15) / 16;
-  auto kern = logpdf_mfma_kernel<NB, TRI, SHIFT, 0, LOGMVN>;
+  auto kern = logpdf_mfma_kernel<NB, TRI, SHIFT, 0, LOGMVN, PAD>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -52,7 +55,7 @@ static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, const doubl
   long blocks = num_cus;
   if (blocks > (num_tiles + 15) / 16) blocks = (num_tiles + 15) / 16;  // >= 16 tiles each
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds_bytes, stream, X, (long)N,
-                     (long)ldx, frags, shift, bias, ep, out, num_tiles);
+                     (long)ldx, frags, shift, bias, ep, out, num_tiles, d);
   return hipGetLastError();
 }
 
@@ -63,14 +66,16 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
 {
   if (N <= 0) return hipSuccess;
   const bool logmvn = ep.kind == CUSMC_MVN && !ep.out_density;
-#define CUSMC_EPI(nb, t, s)                                                                       \
-  (logmvn ? launch_nb<nb, t, s, true>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream) \
-          : launch_nb<nb, t, s, false>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream))
+  const bool pad = mfma_needs_pad(d, X, ldx);
+#define CUSMC_PADV(nb, t, s, l)                                                                   \
+  (pad ? launch_nb<nb, t, s, l, true>(X, N, ldx, d, frags, shift, bias, ep, out, num_cus, stream) \
+       : launch_nb<nb, t, s, l, false>(X, N, ldx, d, frags, shift, bias, ep, out, num_cus, stream))
+#define CUSMC_EPI(nb, t, s) (logmvn ? CUSMC_PADV(nb, t, s, true) : CUSMC_PADV(nb, t, s, false))
 #define CUSMC_CASE(nb)                                                                            \
   case nb:                                                                                        \
     if (!tri) return CUSMC_EPI(nb, false, false);                                                 \
     return has_shift ? CUSMC_EPI(nb, true, true) : CUSMC_EPI(nb, true, false);
-  switch (d / 16) {
+  switch ((d + 15) / 16) {
     CUSMC_CASE(1)
     CUSMC_CASE(2)
     CUSMC_CASE(3)
@@ -82,6 +87,7 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
   }
 #undef CUSMC_CASE
 #undef CUSMC_EPI
+#undef CUSMC_PADV
   return hipErrorInvalidValue;
 }
 

@@ -40,6 +40,7 @@ namespace cusmc {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));  // rows are 8-byte aligned in general
 
 __host__ __device__ constexpr int pi_k(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
 
@@ -58,6 +59,11 @@ __device__ __forceinline__ double finish(double q, const Epilogue &ep)
 // stay live across the tile loop, and at d = 64 the loop owns the whole register file (80 factor +
 // 96 operand + 32 accumulator VGPRs) -- with them hipcc spilled one operand pair and drained
 // vmcnt to reload it on every third tile.
+// PAD = true serves every other d in (16, 128] and every alignment: the factor is zero-padded to
+// 16*NB on the host, the first NB-1 k-blocks are loaded as usual (16-byte loads that need no more
+// than the rows' natural 8-byte alignment), and the last k-block is loaded element by element with
+// the column clamped into the row and the columns >= d replaced by zero -- never read from the
+// next row (whose values are not this particle's and might not be finite) nor past the end of X.
 // ABL is for scripts/calib/ablate.hip only (0 in the library): 1 = no global loads inside the tile
 // loop, 2 = no MFMAs, 3 = no cross-lane reduction, 4 = clock stamps, 5 = 1 + 4.  It exists to
 // attribute time.
@@ -137,11 +143,11 @@ __host__ __device__ constexpr int mfma_sets()  // operand register sets in rotat
 #endif
 }
 
-template <int NB, bool TRI, bool SHIFT, int ABL = 0, bool LOGMVN = false>
+template <int NB, bool TRI, bool SHIFT, int ABL = 0, bool LOGMVN = false, bool PAD = false>
 __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     const double *__restrict__ X, long N, long ldx, const double *__restrict__ frags,
     const double *__restrict__ shift, const double *__restrict__ bias, Epilogue ep,
-    double *__restrict__ out, long num_tiles)
+    double *__restrict__ out, long num_tiles, int d_true = 16 * NB)
 {
   constexpr int THREADS = mfma_threads<NB>();
   constexpr bool STAMP = ABL == 4 || ABL == 5;
@@ -213,14 +219,36 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   // loads tile tt; past the end it re-reads the workgroup's first tile (an L2 hit, result
   // unused): a branch around the prefetch would make hipcc's s_waitcnt placement assume the
   // no-prefetch path and wait for the prefetched loads at the head of every tile.
+  // PAD: per-lane byte offsets of the last k-block's four elements (k = pi(s,h)), column clamped to
+  // d-1, for a full tile and for the last one; `keep[s]` = the column exists
+  unsigned pad_off[4] = {0, 0, 0, 0}, pad_off_last[4] = {0, 0, 0, 0};
+  bool keep[4] = {true, true, true, true};
+  if constexpr (PAD) {
+    const int rem = d_true - 16 * (NB - 1);  // columns of the last block that exist: 1..16
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int col = pi_k(s4, h);
+      keep[s4] = col < rem;
+      const long cc = 16 * (NB - 1) + (col < rem ? col : rem - 1);
+      pad_off[s4] = (unsigned)((long)p * ldx + cc) * 8u;
+      pad_off_last[s4] = (unsigned)((long)(p < tail_rows ? p : tail_rows - 1) * ldx + cc) * 8u;
+    }
+  }
   auto load_tile = [&](unsigned tt, v2d(&a)[NB][2]) {
     const long t = tt < nt ? tt : blockIdx.x;
     const char *base = reinterpret_cast<const char *>(X) + t * tile_bytes;  // scalar
     const unsigned off = t == last ? lane_off_last : lane_off;
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      a[kb][0] = *reinterpret_cast<const v2d *>(base + off + 128 * kb);
-      a[kb][1] = *reinterpret_cast<const v2d *>(base + off + 128 * kb + 64);
+    for (int kb = 0; kb < (PAD ? NB - 1 : NB); ++kb) {
+      a[kb][0] = *reinterpret_cast<const v2d_a8 *>(base + off + 128 * kb);
+      a[kb][1] = *reinterpret_cast<const v2d_a8 *>(base + off + 128 * kb + 64);
+    }
+    if constexpr (PAD) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const double v = *reinterpret_cast<const double *>(base + (t == last ? pad_off_last[s4] : pad_off[s4]));
+        a[NB - 1][s4 >> 1][s4 & 1] = keep[s4] ? v : 0.0;
+      }
     }
   };
 

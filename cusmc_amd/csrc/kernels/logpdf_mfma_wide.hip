@@ -51,11 +51,23 @@ __host__ __device__ constexpr int wide_waves(int nb) { return wide_pairs(nb) * w
 __host__ __device__ constexpr int wide_gp(int nb) { return 32 * wide_row_halves(nb); }  // particles per group
 __host__ __device__ constexpr int wide_pi(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
 
+// Block count the kernel runs d with: 8 (d = 128 only: below that the tile kernel is the better
+// fit), 12 up to d = 192, 16 up to d = 256.
+int mfma_wide_nb(int d) { return d <= 128 ? 8 : d <= 192 ? 12 : 16; }
+
+// d = 128, 192, 256 with 16-byte aligned rows run unpadded; every other d in (128, 256] and every
+// other alignment runs the padded variant (PAD: zero-padded factor, columns >= d masked to zero
+// where the compute waves pick their operands out of LDS).
 bool mfma_wide_supported(int d, const void *X, int64_t ldx)
 {
-  if (d != 128 && d != 192 && d != 256) return false;
+  if (d < 128 || d > 256) return false;
+  if (d == 128 && ((uintptr_t)X % 16 != 0 || ldx % 2 != 0)) return false;  // tile kernel, padded
   // a group of <= 64 rows is addressed through one 32-bit buffer descriptor
-  return ((uintptr_t)X % 16 == 0) && (ldx % 2 == 0) && (ldx < (1L << 21));
+  return ldx < (1L << 21);
+}
+static bool wide_needs_pad(int d, const void *X, int64_t ldx)
+{
+  return d != 16 * mfma_wide_nb(d) || (uintptr_t)X % 16 != 0 || ldx % 2 != 0;
 }
 
 // fragments in the stream of pair q (kernel loop order: kb, s, live members)
@@ -112,11 +124,12 @@ struct WideStreams { int byte_off[8]; };  // start of each pair's fragment strea
 
 // ABL (scripts/calib only; 0 in the library): 1 = fragments not re-fetched, 2 = next group's rows
 // not fetched, 3 = neither.  Attribution of stall time; results are wrong by construction.
-template <int NB, bool TRI, bool SHIFT, int ABL = 0>
+template <int NB, bool TRI, bool SHIFT, int ABL = 0, bool PAD = false>
 __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_kernel(
     const double *__restrict__ X, long N, long ldx, const double *__restrict__ frags,
     WideStreams streams, long frag_bytes, const double *__restrict__ shift,
-    const double *__restrict__ bias, Epilogue ep, double *__restrict__ out, long num_groups)
+    const double *__restrict__ bias, Epilogue ep, double *__restrict__ out, long num_groups,
+    int d_true = 16 * NB)
 {
   constexpr int P = wide_pairs(NB);
   constexpr int WAVES = wide_waves(NB);  // compute waves; wave WAVES is the loader
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
     // and the DMA puts lane l's chunk at slab + 16 l.  Global side: voffset = (p ldx + 2h) 8
     // (loop-invariant), soffset = (16 t ldx + 16 kb + 8 h2) 8 (scalar).  The compute waves read
     // a slab back with one conflict-free ds_read_b128 per lane.
-    const int d_bytes = 128 * NB;
+    const int d_bytes = PAD ? 8 * d_true : 128 * NB;  // (PAD: what lies past the last row's end reads as zero)
     const int voff = (int)(((long)(lane & 15) * ldx + 2 * (lane >> 4)) * 8);
     const int tile_bytes = (int)(16 * ldx * 8);
     auto stage_group = [&](long g, double *buf) {
@@ -248,6 +261,16 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         double r0 = xcur[s >> 1][0][s & 1], r1 = xcur[s >> 1][1][s & 1];
+        if constexpr (PAD) {
+          // columns >= d of the padded k-blocks hold the next row's leading values (or zeros past
+          // the end of X): not this particle's, possibly not finite -- they must not reach the
+          // matrix cores even against a zero factor column
+          if (kb >= d_true / 16) {  // uniform
+            const bool keepc = 16 * kb + wide_pi(s, h) < d_true;
+            r0 = keepc ? r0 : 0.0;
+            r1 = keepc ? r1 : 0.0;
+          }
+        }
         if (TRI && SHIFT) {
           const double sh = sShift[16 * kb + wide_pi(s, h)];
           r0 -= sh;
@@ -324,12 +347,12 @@ static WideStreams wide_streams()
   return st;
 }
 
-template <int NB, bool TRI, bool SHIFT>
-static hipError_t launch_wide(const double *X, int64_t N, int64_t ldx, const double *frags,
+template <int NB, bool TRI, bool SHIFT, bool PAD>
+static hipError_t launch_wide(const double *X, int64_t N, int64_t ldx, int d, const double *frags,
                               const double *shift, const double *bias, const Epilogue &ep,
                               double *out, int num_cus, hipStream_t stream)
 {
-  auto kern = logpdf_mfma_wide_kernel<NB, TRI, SHIFT>;
+  auto kern = logpdf_mfma_wide_kernel<NB, TRI, SHIFT, 0, PAD>;
   const size_t lds_bytes = wide_lds_bytes(NB);
   static bool configured = false;
   if (!configured) {
@@ -344,7 +367,7 @@ static hipError_t launch_wide(const double *X, int64_t N, int64_t ldx, const dou
   if (blocks > num_groups) blocks = num_groups;
   const long frag_bytes = (long)mfma_wide_frag_doubles(NB, TRI) * 8;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * (wide_waves(NB) + 1)), lds_bytes, stream, X, (long)N,
-                     (long)ldx, frags, wide_streams<NB, TRI>(), frag_bytes, shift, bias, ep, out, num_groups);
+                     (long)ldx, frags, wide_streams<NB, TRI>(), frag_bytes, shift, bias, ep, out, num_groups, d);
   return hipGetLastError();
 }
 
@@ -384,17 +407,21 @@ hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int 
                                    int num_cus, hipStream_t stream)
 {
   if (N <= 0) return hipSuccess;
+  const bool pad = wide_needs_pad(d, X, ldx);
+#define CUSMC_WPAD(nb, t, s)                                                                       \
+  (pad ? launch_wide<nb, t, s, true>(X, N, ldx, d, frags, shift, bias, ep, out, num_cus, stream)   \
+       : launch_wide<nb, t, s, false>(X, N, ldx, d, frags, shift, bias, ep, out, num_cus, stream))
 #define CUSMC_WIDE(nb)                                                                             \
   case nb:                                                                                         \
-    if (!tri) return launch_wide<nb, false, false>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream); \
-    return has_shift ? launch_wide<nb, true, true>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream)  \
-                     : launch_wide<nb, true, false>(X, N, ldx, frags, shift, bias, ep, out, num_cus, stream);
-  switch (d / 16) {
+    if (!tri) return CUSMC_WPAD(nb, false, false);                                                 \
+    return has_shift ? CUSMC_WPAD(nb, true, true) : CUSMC_WPAD(nb, true, false);
+  switch (mfma_wide_nb(d)) {
     CUSMC_WIDE(8)
     CUSMC_WIDE(12)
     CUSMC_WIDE(16)
   }
 #undef CUSMC_WIDE
+#undef CUSMC_WPAD
   return hipErrorInvalidValue;
 }
 

@@ -38,6 +38,7 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
 
 // --- kernels/logpdf_mfma_wide.hip : d in {128, 192, 256}, output blocks split over 4 waves ------
 bool mfma_wide_supported(int d, const void *X, int64_t ldx);
+int mfma_wide_nb(int d);  // 16-column blocks the wide kernel runs d with (8, 12 or 16)
 size_t mfma_wide_frag_doubles(int nb, bool tri);
 void mfma_wide_pack_frags(const double *M, int d, bool tri, double *frags);
 hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int d, bool tri,

@@ -221,6 +221,50 @@ def test_tile_deal_boundaries(cs, oracle, d, N, dist):
     D.close()
 
 
+@pytest.mark.parametrize("d", [17, 24, 31, 40, 65, 81, 100, 127, 129, 144, 150, 191, 200, 255])
+@pytest.mark.parametrize("dist", ["mvn", "mvt"])
+def test_padded_dimensions(cs, oracle, d, dist):
+    """d not a multiple of 16 runs on the matrix cores with the factor zero-padded: every output
+    against the hoisted-factor oracle (odd N: short last tile; odd d: rows only 8-byte aligned),
+    the general-F reweight form too, and no leakage between neighbouring rows -- a row of NaN / Inf
+    makes exactly its own output NaN, whatever sits in the rows around it."""
+    import torch
+    rng = np.random.default_rng(3 * d)
+    N = 16 * 256 * 2 + 11
+    sigma, mu = spd(rng, d), rng.standard_normal(d)
+    Xh = mu + rng.standard_normal((N, d))
+    bad = [0, 5, 777, N - 1]
+    Xh[bad[0]] = np.nan
+    Xh[bad[1], 0] = np.inf       # first column of a row: what the previous row's padded block would touch
+    Xh[bad[2], d - 1] = np.nan
+    Xh[bad[3]] = np.inf
+    X = torch.from_numpy(Xh).cuda()
+    out = torch.full((N + 8,), -1.0, dtype=torch.float64, device="cuda")
+    D = (cs.MultiVariateNormalDistribution(mu, sigma) if dist == "mvn"
+         else cs.MultiVariateTStudentDistribution(mu, sigma, 4.0))
+    D.ctx.use_torch_stream()
+    D.pdf_dev(X, out[:N])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.all(got[N:] == -1.0)
+    good = np.ones(N, bool); good[bad] = False
+    assert not np.isfinite(got[:N][~good]).any()
+    assert np.isfinite(got[:N][good]).all()
+    want = oracle.logpdf_hoisted(Xh[good], mu, sigma, None, dist, 4.0)
+    assert rel_err(got[:N][good], want) < RTOL
+    # reweight_G with a general F (dense affine plan, padded likewise)
+    F = np.eye(d) + 0.05 * rng.standard_normal((d, d))
+    y = rng.standard_normal(d)
+    Xg = torch.from_numpy(Xh[good][:3000]).cuda().contiguous()
+    w = torch.empty(Xg.shape[0], dtype=torch.float64, device="cuda")
+    D.reweight_dev(Xg, y, F, w, log=True)
+    torch.cuda.synchronize()
+    R = y[None, :] - Xh[good][:3000] @ F.T
+    want2 = oracle.logpdf_hoisted(R, None, sigma, None, dist, 4.0)
+    assert rel_err(w.cpu().numpy(), want2) < RTOL
+    D.close()
+
+
 def test_full_size_properties_student_t(cs, oracle):
     """BASELINE configs[3] shape (nu = 4, 1e6 x d = 64) through the same size-independent properties."""
     import torch
