@@ -574,11 +574,19 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
     return CUSMC_OK;
   }
   if (cusmc::propagate_mfma_supported(d, X_prev_dev, X_out_dev)) {
-    // device image: [frags(Q) | frags(G) | m0], fragments in the MFMA operand order
-    const size_t nf = (size_t)cusmc::mfma_num_frags(d / 16, false) * 64;
-    std::vector<double> img(2 * nf + d, 0.0);
-    cusmc::mfma_pack_frags(Q, d, false, img.data());
-    if (G) cusmc::mfma_pack_frags(G, d, false, img.data() + nf);
+    // device image: [frags(Q) | frags(G) | m0], fragments in the MFMA operand order; factors
+    // zero-padded to 16*ceil(d/16)
+    const int nb = (d + 15) / 16, dp = 16 * nb;
+    const size_t nf = (size_t)cusmc::mfma_num_frags(nb, false) * 64;
+    std::vector<double> img(2 * nf + d, 0.0), Mp;
+    auto pack = [&](const double *M, double *dst) {
+      if (dp == d) { cusmc::mfma_pack_frags(M, d, false, dst); return; }
+      Mp.assign((size_t)dp * dp, 0.0);
+      for (int i = 0; i < d; ++i) std::copy(M + (size_t)i * d, M + (size_t)(i + 1) * d, Mp.begin() + (size_t)i * dp);
+      cusmc::mfma_pack_frags(Mp.data(), dp, false, dst);
+    };
+    pack(Q, img.data());
+    if (G) pack(G, img.data() + nf);
     if (m0) std::copy(m0, m0 + d, img.begin() + 2 * nf);
     if (int rc = ctx->scratch[4].reserve(img.size() * 8)) return rc;
     if (int rc = ctx->ring.upload(ctx->scratch[4].p, img.data(), img.size() * 8, ctx->stream)) return rc;
@@ -588,7 +596,7 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
                                          count, X_out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
-  if (d > 159) return fail(CUSMC_ERANGE, "proposal kernels support d <= 159 or d in {16,32,48,64} (got %d)", d);
+  if (d > 159) return fail(CUSMC_ERANGE, "dense proposal kernels support d <= 159 (got %d); diagonal G and Q have no limit", d);
   // device image: [Q | G | m0]
   if (int rc = ctx->scratch[4].reserve((2 * dd + d) * 8)) return rc;
   if (int rc = upload_small(ctx, ctx->scratch[4], 0, Q, dd)) return rc;

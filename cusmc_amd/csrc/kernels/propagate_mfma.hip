@@ -1,4 +1,4 @@
-// Proposal draws for d = 16*NB <= 64 on the f64 matrix cores: gather + RNG + two dense mat-vecs
+// Proposal draws for 16 <= d <= 128 on the f64 matrix cores: gather + RNG + two dense mat-vecs
 // per particle become   X_out^T = Q Xi^T [.* C] + G X_gathered^T   (d x d times d x 16 per tile).
 // Same contract, RNG counters and reference functions as kernels/propagate.hip
 // (propagate_K: src/mcmc.cpp:112-140 -> sample(): src/statistics.cc.cpp:224-259, 355-412; replaces
@@ -26,6 +26,7 @@ namespace cusmc {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));  // rows are 8-byte aligned in general
 
 __host__ __device__ constexpr int pm_pi(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
 
@@ -63,32 +64,42 @@ static __device__ __attribute__((noinline)) double pm_chi_square(uint32_t partic
   return 2.0 * g * boost;
 }
 
+// Every 16 <= d <= 128 and any 8-byte aligned batch.  d <= 96 keeps both factors in LDS (one
+// launch); 96 < d <= 128 runs two launches, one factor each (131 KB at d = 128): first
+// x = [diag(c)] Q xi, then x += G x_prev[a].
 bool propagate_mfma_supported(int d, const void *X_prev, const void *X_out)
 {
-  if (d % 16 != 0 || d > 64) return false;
-  return ((uintptr_t)X_prev % 16 == 0) && ((uintptr_t)X_out % 8 == 0);
+  return d >= 16 && d <= 128 && (uintptr_t)X_prev % 8 == 0 && (uintptr_t)X_out % 8 == 0;
 }
 
-// GATHER = true: propagate (G x_prev[a]); false: initial / R-level draw (+ m0).
-template <int NB, bool MVT, bool GATHER>
+// MODE 0: initial / R-level draw     x = [diag(c)] Q xi + m0
+//      1: propagate, one launch      x = [diag(c)] Q xi + G x_prev[a]
+//      2: first half of two          x = [diag(c)] Q xi
+//      3: second half                x += G x_prev[a]
+// PAD: d is not 16*NB (factors zero-padded on the host) or rows are not 16-byte aligned: the last
+// k-block of the gathered row is loaded element by element, column clamped into the row, columns
+// >= d zeroed; normals for pairs past d are not drawn; outputs past d are not stored.
+template <int NB, bool MVT, int MODE, bool PAD>
 __global__ __launch_bounds__(512) void propagate_mfma_kernel(
     float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
     const double *__restrict__ fragsQ, const double *__restrict__ fragsG, const double *__restrict__ m0,
-    double scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t domain, uint32_t first, uint32_t count,
-    double *__restrict__ X_out, long num_tiles)
+    int d, double scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t domain, uint32_t first,
+    uint32_t count, double *__restrict__ X_out, long num_tiles)
 {
   constexpr int D = 16 * NB;
   constexpr int NFRAG = 4 * NB * NB;
+  constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0;
+  constexpr bool SPLIT_ACC = (MVT && HAS_Q && HAS_G) || HAS_M0 || MODE == 3;  // accG separate from accQ
   extern __shared__ double lds[];
-  double *sQ = lds;                                  // NFRAG x 64
-  double *sG = sQ + NFRAG * 64;                      // NFRAG x 64 (GATHER) or m0 (D doubles)
-  int *sNext = reinterpret_cast<int *>(sG + (GATHER ? NFRAG * 64 : D));
+  double *sQ = lds;                                  // NFRAG x 64 (HAS_Q)
+  double *sG = sQ + (HAS_Q ? NFRAG * 64 : 0);        // NFRAG x 64 (HAS_G) or m0 padded to D (HAS_M0)
+  int *sNext = reinterpret_cast<int *>(sG + (HAS_G ? NFRAG * 64 : (HAS_M0 ? D : 0)));
 
   for (int i = threadIdx.x; i < NFRAG * 32; i += 512) {
-    reinterpret_cast<v2d *>(sQ)[i] = reinterpret_cast<const v2d *>(fragsQ)[i];
-    if (GATHER) reinterpret_cast<v2d *>(sG)[i] = reinterpret_cast<const v2d *>(fragsG)[i];
+    if (HAS_Q) reinterpret_cast<v2d *>(sQ)[i] = reinterpret_cast<const v2d *>(fragsQ)[i];
+    if (HAS_G) reinterpret_cast<v2d *>(sG)[i] = reinterpret_cast<const v2d *>(fragsG)[i];
   }
-  if (!GATHER && threadIdx.x < D) sG[threadIdx.x] = m0[threadIdx.x];
+  if (HAS_M0 && threadIdx.x < D) sG[threadIdx.x] = (int)threadIdx.x < d ? m0[threadIdx.x] : 0.0;
   if (threadIdx.x == 0) *sNext = 0;
   __syncthreads();
 
@@ -102,6 +113,7 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
     return __builtin_amdgcn_readfirstlane(k);
   };
   int lds_lane = lane;  // opaque per tile: keeps the factor reads as in-loop ds_read_b64
+  const int rem = d - 16 * (NB - 1);  // columns of the last k-block that exist (16 unless padded)
 
   for (int k = grab(); k < my_tiles; k = grab()) {
     asm volatile("" : "+v"(lds_lane));
@@ -112,34 +124,47 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
 
     // ancestor row: two 16-byte loads per k-block (issued first; the RNG below hides them)
     v2d xg[NB][2];
-    if (GATHER) {
+    if constexpr (HAS_G) {
       const uint32_t anc = a ? a[live ? local : (long)count - 1] : gi;
-      const double *src = X_prev + (long)anc * D + 2 * h;
+      const double *row = X_prev + (long)anc * d;
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) {
-        xg[kb][0] = *reinterpret_cast<const v2d *>(src + 16 * kb);
-        xg[kb][1] = *reinterpret_cast<const v2d *>(src + 16 * kb + 8);
+      for (int kb = 0; kb < (PAD ? NB - 1 : NB); ++kb) {
+        xg[kb][0] = *reinterpret_cast<const v2d_a8 *>(row + 16 * kb + 2 * h);
+        xg[kb][1] = *reinterpret_cast<const v2d_a8 *>(row + 16 * kb + 8 + 2 * h);
+      }
+      if constexpr (PAD) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int col = pm_pi(s, h);
+          const double v = row[16 * (NB - 1) + (col < rem ? col : rem - 1)];
+          xg[NB - 1][s >> 1][s & 1] = col < rem ? v : 0.0;
+        }
       }
     }
     // normals in operand order: xi[kb][s] = xi_p[16 kb + pi(s, h)]
     double xi[NB][4];
+    if constexpr (HAS_Q) {
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      pm_normal_pair(philox4x32_10(gi, (uint32_t)(8 * kb + h), step, domain, k0, k1), xi[kb][0], xi[kb][1]);
-      pm_normal_pair(philox4x32_10(gi, (uint32_t)(8 * kb + 4 + h), step, domain, k0, k1), xi[kb][2], xi[kb][3]);
+      for (int kb = 0; kb < NB; ++kb) {
+        xi[kb][0] = xi[kb][1] = xi[kb][2] = xi[kb][3] = 0.0;
+        if (!PAD || 16 * kb + 2 * h < d)
+          pm_normal_pair(philox4x32_10(gi, (uint32_t)(8 * kb + h), step, domain, k0, k1), xi[kb][0], xi[kb][1]);
+        if (!PAD || 16 * kb + 8 + 2 * h < d)
+          pm_normal_pair(philox4x32_10(gi, (uint32_t)(8 * kb + 4 + h), step, domain, k0, k1), xi[kb][2], xi[kb][3]);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xi[kb][s] *= scale;
+        for (int s = 0; s < 4; ++s) xi[kb][s] *= scale;
+      }
     }
 
     v4d accQ[NB], accG[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
       accQ[cb] = v4d{0.0, 0.0, 0.0, 0.0};
-      if (GATHER) {
-        accG[cb] = v4d{0.0, 0.0, 0.0, 0.0};
-      } else {  // C rows are output dims h + 4r of block cb
+      if (HAS_M0) {  // C rows are output dims h + 4r of block cb
         const double *b = sG + 16 * cb + h;
         accG[cb] = v4d{b[0], b[4], b[8], b[12]};
+      } else {
+        accG[cb] = v4d{0.0, 0.0, 0.0, 0.0};
       }
     }
     int f = 0;
@@ -149,9 +174,9 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb, ++f) {
-          accQ[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sQ[f * 64 + lds_lane], xi[kb][s], accQ[cb], 0, 0, 0);
-          if (GATHER) {
-            v4d &dst = MVT ? accG[cb] : accQ[cb];  // mvn: one accumulator takes both products
+          if (HAS_Q) accQ[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sQ[f * 64 + lds_lane], xi[kb][s], accQ[cb], 0, 0, 0);
+          if (HAS_G) {
+            v4d &dst = SPLIT_ACC ? accG[cb] : accQ[cb];  // mvn, one launch: one accumulator takes both products
             dst = __builtin_amdgcn_mfma_f64_16x16x4f64(sG[f * 64 + lds_lane], xg[kb][s >> 1][s & 1], dst, 0, 0, 0);
           }
         }
@@ -159,17 +184,16 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
     }
     // x_out[p][16 cb + h + 4 r]
     if (live) {
-      double *dst = X_out + local * D + h;
+      double *dst = X_out + local * d + h;
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double v = accQ[cb][r];
-          if (MVT) {
-            const uint32_t j = (uint32_t)(16 * cb + h + 4 * r);
-            v *= sqrt((double)nu / pm_chi_square(gi, j, step, k0, k1, nu));
-          }
-          if (MVT || !GATHER) v += accG[cb][r];
+          const int j = 16 * cb + h + 4 * r;
+          if (PAD && j >= d) continue;
+          double v = HAS_Q ? accQ[cb][r] : dst[16 * cb + 4 * r];
+          if (MVT && HAS_Q) v *= sqrt((double)nu / pm_chi_square(gi, (uint32_t)j, step, k0, k1, nu));
+          if (SPLIT_ACC) v += accG[cb][r];
           dst[16 * cb + 4 * r] = v;
         }
       }
@@ -177,15 +201,16 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
   }
 }
 
-template <int NB, bool MVT, bool GATHER>
+template <int NB, bool MVT, int MODE, bool PAD>
 static hipError_t launch_pm(float nu, const double *X_prev, const uint32_t *a, const double *fragsQ,
-                            const double *fragsG, const double *m0, double scale, uint64_t seed, uint32_t step,
-                            uint32_t domain, uint32_t first, uint32_t count, double *X_out, int num_cus,
-                            hipStream_t stream)
+                            const double *fragsG, const double *m0, int d, double scale, uint64_t seed,
+                            uint32_t step, uint32_t domain, uint32_t first, uint32_t count, double *X_out,
+                            int num_cus, hipStream_t stream)
 {
   constexpr int NFRAG = 4 * NB * NB;
-  const size_t lds_bytes = (size_t)(NFRAG * 64 + (GATHER ? NFRAG * 64 : 16 * NB) + 2) * sizeof(double);
-  auto kern = propagate_mfma_kernel<NB, MVT, GATHER>;
+  constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0;
+  const size_t lds_bytes = (size_t)((HAS_Q ? NFRAG * 64 : 0) + (HAS_G ? NFRAG * 64 : (HAS_M0 ? 16 * NB : 0)) + 2) * sizeof(double);
+  auto kern = propagate_mfma_kernel<NB, MVT, MODE, PAD>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -195,10 +220,12 @@ static hipError_t launch_pm(float nu, const double *X_prev, const uint32_t *a, c
   long blocks = num_cus;
   if (blocks > num_tiles) blocks = num_tiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, stream, nu, X_prev, a, fragsQ, fragsG, m0,
-                     scale, (uint32_t)seed, (uint32_t)(seed >> 32), step, domain, first, count, X_out, num_tiles);
+                     d, scale, (uint32_t)seed, (uint32_t)(seed >> 32), step, domain, first, count, X_out, num_tiles);
   return hipGetLastError();
 }
 
+// fragsQ / fragsG: mfma_pack_frags of the factors zero-padded to 16*ceil(d/16) (fragsG == NULL: the
+// initial draw, + m0).
 hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const uint32_t *a,
                                  const double *fragsQ, const double *fragsG, const double *m0, int d,
                                  double scale, uint64_t seed, uint32_t step, uint32_t domain,
@@ -207,24 +234,27 @@ hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const
 {
   if (count == 0) return hipSuccess;
   const bool mvt = kind == CUSMC_MVT, gather = fragsG != nullptr;
-#define CUSMC_PM(nb)                                                                                        \
-  case nb:                                                                                                  \
-    if (gather)                                                                                             \
-      return mvt ? launch_pm<nb, true, true>(nu, X_prev, a, fragsQ, fragsG, m0, scale, seed, step, domain,  \
-                                             first, count, X_out, num_cus, stream)                          \
-                 : launch_pm<nb, false, true>(nu, X_prev, a, fragsQ, fragsG, m0, scale, seed, step, domain, \
-                                              first, count, X_out, num_cus, stream);                        \
-    return mvt ? launch_pm<nb, true, false>(nu, X_prev, a, fragsQ, fragsG, m0, scale, seed, step, domain,   \
-                                            first, count, X_out, num_cus, stream)                           \
-               : launch_pm<nb, false, false>(nu, X_prev, a, fragsQ, fragsG, m0, scale, seed, step, domain,  \
-                                             first, count, X_out, num_cus, stream);
-  switch (d / 16) {
-    CUSMC_PM(1)
-    CUSMC_PM(2)
-    CUSMC_PM(3)
-    CUSMC_PM(4)
+  const bool pad = d % 16 != 0 || (gather && (uintptr_t)X_prev % 16 != 0);
+#define CUSMC_ARGS nu, X_prev, a, fragsQ, fragsG, m0, d, scale, seed, step, domain, first, count, X_out, num_cus, stream
+#define CUSMC_PMV(nb, mode)                                                                                  \
+  (mvt ? (pad ? launch_pm<nb, true, mode, true>(CUSMC_ARGS) : launch_pm<nb, true, mode, false>(CUSMC_ARGS))  \
+       : (pad ? launch_pm<nb, false, mode, true>(CUSMC_ARGS) : launch_pm<nb, false, mode, false>(CUSMC_ARGS)))
+#define CUSMC_PM1(nb) /* both factors fit the LDS */ \
+  case nb: return gather ? CUSMC_PMV(nb, 1) : CUSMC_PMV(nb, 0);
+#define CUSMC_PM2(nb) /* one factor per launch */                                   \
+  case nb: {                                                                        \
+    if (!gather) return CUSMC_PMV(nb, 0);                                           \
+    const hipError_t e = CUSMC_PMV(nb, 2);                                          \
+    return e != hipSuccess ? e : CUSMC_PMV(nb, 3);                                  \
   }
-#undef CUSMC_PM
+  switch ((d + 15) / 16) {
+    CUSMC_PM1(1) CUSMC_PM1(2) CUSMC_PM1(3) CUSMC_PM1(4) CUSMC_PM1(5) CUSMC_PM1(6)
+    CUSMC_PM2(7) CUSMC_PM2(8)
+  }
+#undef CUSMC_PM1
+#undef CUSMC_PM2
+#undef CUSMC_PMV
+#undef CUSMC_ARGS
   return hipErrorInvalidValue;
 }
 

@@ -362,7 +362,7 @@ def test_resampler_full_size_properties(cs):
 
 # --- draws and the filter ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("d", [2, 5, 8, 16, 33, 64])
+@pytest.mark.parametrize("d", [2, 5, 8, 16, 33, 64, 81, 100, 128])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 5.0), ("mvt", 1.5)])
 def test_draws_match_oracle(cs, oracle, d, dist, nu):
     """Same Philox counters, same transform: the draws agree to rounding (libm vs ocml log/
@@ -380,11 +380,12 @@ def test_draws_match_oracle(cs, oracle, d, dist, nu):
     D.close()
 
 
-@pytest.mark.parametrize("d", [2, 8, 16, 32, 48, 64])
+@pytest.mark.parametrize("d", [2, 8, 16, 17, 32, 40, 48, 64, 65, 80, 96, 100, 113, 128])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0)])
 def test_propagate_matches_oracle(cs, oracle, d, dist, nu):
     """propagate_K (src/mcmc.cpp:112-140): gather by ancestor + G x + Q xi, device-resident, against the
-    oracle on the same Philox counters; d = 16..64 take the MFMA kernel, the others the generic one.
+    oracle on the same Philox counters; 16 <= d <= 128 take the MFMA kernel (padded when d is not a
+    multiple of 16, two launches above d = 96), the others the generic one.
     Also the shard identity the multi-GPU path relies on: rows [first, first+count) computed alone
     equal the same rows of the full launch."""
     import torch
