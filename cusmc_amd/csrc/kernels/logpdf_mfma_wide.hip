@@ -1,4 +1,4 @@
-// Batched MVN / Student-t log-density for large d = 16*NB, NB in {8, 12, 16} (d = 128, 192, 256):
+// Batched MVN / Student-t log-density for large d: 128 < d <= 256, run as NB = 12 or 16 blocks of 16:
 // the regime where (X - mu) L^-T is a genuine dense GEMM and the kernel is bound by the f64 matrix
 // cores, not by HBM (d = 256: 2056 B and ~70 kflop per particle = 34 flop/B against a machine
 // balance of 9.8).  Same contract and same reference functions as kernels/logpdf_mfma_kernel.h:
@@ -51,19 +51,19 @@ __host__ __device__ constexpr int wide_waves(int nb) { return wide_pairs(nb) * w
 __host__ __device__ constexpr int wide_gp(int nb) { return 32 * wide_row_halves(nb); }  // particles per group
 __host__ __device__ constexpr int wide_pi(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
 
-// Block count the kernel runs d with: 8 (d = 128 only: below that the tile kernel is the better
-// fit), 12 up to d = 192, 16 up to d = 256.
-int mfma_wide_nb(int d) { return d <= 128 ? 8 : d <= 192 ? 12 : 16; }
+// Block count the kernel runs d with: 12 up to d = 192, 16 up to d = 256.  (d = 128 belongs to the
+// tile kernel: 297 us against 382 us here for 1e6 particles -- at 8 blocks the split over waves
+// leaves each wave too little work per k-block to cover its fragment loads.)
+int mfma_wide_nb(int d) { return d <= 192 ? 12 : 16; }
 
-// d = 128, 192, 256 with 16-byte aligned rows run unpadded; every other d in (128, 256] and every
+// d = 192, 256 with 16-byte aligned rows run unpadded; every other d in (128, 256] and every
 // other alignment runs the padded variant (PAD: zero-padded factor, columns >= d masked to zero
 // where the compute waves pick their operands out of LDS).
 bool mfma_wide_supported(int d, const void *X, int64_t ldx)
 {
-  if (d < 128 || d > 256) return false;
-  if (d == 128 && ((uintptr_t)X % 16 != 0 || ldx % 2 != 0)) return false;  // tile kernel, padded
+  (void)X;
   // a group of <= 64 rows is addressed through one 32-bit buffer descriptor
-  return ldx < (1L << 21);
+  return d > 128 && d <= 256 && ldx < (1L << 21);
 }
 static bool wide_needs_pad(int d, const void *X, int64_t ldx)
 {
@@ -416,7 +416,6 @@ hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int 
     if (!tri) return CUSMC_WPAD(nb, false, false);                                                 \
     return has_shift ? CUSMC_WPAD(nb, true, true) : CUSMC_WPAD(nb, true, false);
   switch (mfma_wide_nb(d)) {
-    CUSMC_WIDE(8)
     CUSMC_WIDE(12)
     CUSMC_WIDE(16)
   }

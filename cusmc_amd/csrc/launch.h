@@ -36,7 +36,7 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
                               const double *bias, const Epilogue &ep, double *out, int num_cus,
                               hipStream_t stream);
 
-// --- kernels/logpdf_mfma_wide.hip : d in {128, 192, 256}, output blocks split over 4 waves ------
+// --- kernels/logpdf_mfma_wide.hip : 128 < d <= 256, output blocks split over the waves -----------
 bool mfma_wide_supported(int d, const void *X, int64_t ldx);
 int mfma_wide_nb(int d);  // 16-column blocks the wide kernel runs d with (8, 12 or 16)
 size_t mfma_wide_frag_doubles(int nb, bool tri);
