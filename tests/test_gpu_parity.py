@@ -265,6 +265,46 @@ def test_padded_dimensions(cs, oracle, d, dist):
     D.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_logpdf_random_shapes(cs, oracle, seed):
+    """Dispatch fuzz: random d in [1, 256] (CUSMC_MAX_DIM), random N, row stride, base alignment, distribution and
+    form (centred with mu, or reweight with F = I / general F), every output against the hoisted
+    oracle.  Whatever kernel the library picks, the numbers are the reference's."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(10):
+        d = int(rng.choice([rng.integers(1, 17), rng.integers(17, 129), rng.integers(129, 257)]))
+        N = int(rng.integers(1, 3000))
+        ldx = d + int(rng.choice([0, 0, 1, 2, 7]))
+        off = int(rng.choice([0, 1]))
+        dist = str(rng.choice(["mvn", "mvt"]))
+        nu = float(rng.choice([3.0, 4.0, 2.5, 30.0]))
+        form = str(rng.choice(["pdf", "reweight_I", "reweight_F"]))
+        sigma, mu = spd(rng, d), rng.standard_normal(d)
+        Xh = rng.standard_normal((N, d))
+        buf = torch.full((N * ldx + 2,), float("nan"), dtype=torch.float64, device="cuda")
+        X = buf[off:off + N * ldx].view(N, ldx)[:, :d]
+        X.copy_(torch.from_numpy(Xh))
+        out = torch.full((N + 2,), -7.0, dtype=torch.float64, device="cuda")
+        D = (cs.MultiVariateNormalDistribution(mu, sigma) if dist == "mvn"
+             else cs.MultiVariateTStudentDistribution(mu, sigma, nu))
+        D.ctx.use_torch_stream()
+        if form == "pdf":
+            D.pdf_dev(X, out[:N])
+            want = oracle.logpdf_hoisted(Xh, mu, sigma, None, dist, nu)
+        else:
+            F = np.eye(d) if form == "reweight_I" else np.eye(d) + 0.3 * rng.standard_normal((d, d)) / np.sqrt(d)
+            y = rng.standard_normal(d)
+            D.reweight_dev(X, y, F, out[:N], log=True)
+            want = oracle.logpdf_hoisted(y[None, :] - Xh @ F.T, None, sigma, None, dist, nu)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        tag = (seed, case, d, N, ldx, off, dist, form)
+        assert np.all(got[N:] == -7.0), tag
+        assert rel_err(got[:N], want) < RTOL, tag
+        D.close()
+
+
 def test_full_size_properties_student_t(cs, oracle):
     """BASELINE configs[3] shape (nu = 4, 1e6 x d = 64) through the same size-independent properties."""
     import torch
