@@ -488,6 +488,37 @@ def test_propagate_diagonal_models(cs, oracle, d, dist, nu):
     assert np.allclose(init.cpu().numpy(), want0, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_propagate_random_shapes(cs, oracle, seed):
+    """Dispatch fuzz for the proposal draws: random d in [1, 159], dense or diagonal G and Q, MVN or
+    Student-t, random shard, with and without ancestors, against the oracle's dense loops."""
+    import torch
+    rng = np.random.default_rng(2000 + seed)
+    ctx = cs.api.default_context().use_torch_stream()
+    for case in range(8):
+        d = int(rng.choice([rng.integers(1, 17), rng.integers(17, 129), rng.integers(129, 160)]))
+        N = int(rng.integers(1, 1500))
+        dist = str(rng.choice(["mvn", "mvt"]))
+        nu = float(rng.choice([3.0, 4.0, 1.5]))
+        diag = bool(rng.integers(0, 2))
+        G = np.diag(0.5 + rng.random(d)) if diag else 0.9 * np.eye(d) + 0.3 * rng.standard_normal((d, d)) / np.sqrt(d)
+        Q = np.diag(0.1 + rng.random(d)) if diag else 0.3 * np.eye(d) + 0.2 * rng.standard_normal((d, d)) / np.sqrt(d)
+        Xp = rng.standard_normal((N, d))
+        a = rng.integers(0, N, N).astype(np.uint32)
+        step = int(rng.integers(1, 50))
+        want = oracle.propagate(Xp, a, G, Q, dist, nu, 1.0, seed=seed, step=step)
+        first = int(rng.integers(0, N))
+        count = int(rng.integers(1, N - first + 1))
+        Xd = torch.from_numpy(Xp).cuda()
+        ad = torch.from_numpy(a[first:first + count].astype(np.int32)).cuda()
+        out = torch.full((count + 1, d), float("nan"), dtype=torch.float64, device="cuda")
+        cs.api.propagate_dev(Xd, ad, G, Q, out[:count], dist, nu, 1.0, seed=seed, step=step, first=first, ctx=ctx)
+        torch.cuda.synchronize()
+        tag = (seed, case, d, N, dist, diag, first, count)
+        assert np.allclose(out[:count].cpu().numpy(), want[first:first + count], rtol=1e-9, atol=1e-9), tag
+        assert bool(torch.isnan(out[count]).all()), tag
+
+
 def test_box_muller_accuracy(cs, oracle):
     """The device Box-Muller uses its own ln / sincos(2 pi u) (kernels/smallops.h), the oracle libm's.
     With Q = I and mu = 0 a draw IS the normal variate: 2e5 of them agree to a few ulp of the largest
