@@ -153,10 +153,19 @@ def main():
 
     import cusmc_amd
 
+    # Rehearsal switch for a one-GPU box: CUSMC_BENCH_REHEARSAL=1 puts every rank on device 0 and uses
+    # gloo, to exercise the world > 1 code path (barriers, MAX reduction, the sharded resampler's
+    # all-gather).  Its numbers mean nothing; the driver's multi-GPU runs never set it.
+    rehearsal = os.environ.get("CUSMC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # synthetic batch, resident in HBM before the timed region; every rank owns its own particles
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
@@ -263,7 +272,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one device, gloo)",
             "config": {"workload": "mvn_logpdf fp64: N=%d particles per GPU x d=%d, Sigma = AA^T/d + I "
                                    "(seed 1), device-resident, one launch per step" % (N_PER_GPU, D),
                        "particles_per_gpu": N_PER_GPU, "d": D, "parallelism": "particle-sharded x%d, "
