@@ -409,7 +409,7 @@ def run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p=0
     ctx = default_context()
     X = np.empty((T, N, d))
     w = np.empty((T, N))
-    a = np.empty((T, N), dtype=np.uint32)
+    a = np.empty((T, N), dtype=np.uint32) if return_ancestors else None  # (not copied back unless asked for)
     check(_lib.lib().cusmc_pf_run_host(ctx._h, _ptr(Yt), N, d, T, _ptr(m0), _ptr(C0), _ptr(F), _ptr(G),
                                        _ptr(V), _ptr(W), C.c_float(df), str(resampler).encode(),
                                        str(distribution).encode(), int(B),
