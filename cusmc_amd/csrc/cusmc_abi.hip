@@ -799,7 +799,7 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   // the loop above is only enqueued: fault the output pages in while it runs
   {
     unsigned hw = std::thread::hardware_concurrency();
-    const unsigned threads = hw == 0 ? 4 : (hw > 16 ? 16 : hw);
+    const unsigned threads = getenv("CUSMC_NO_PREFAULT") ? 0 : hw == 0 ? 4 : (hw > 16 ? 16 : hw);  // (switch: for A/B timing)
     std::vector<std::thread> pool;
     prefault_async(pool, X_out, slice * T * 8, threads);
     prefault_async(pool, w_out, (size_t)N * T * 8, threads);
