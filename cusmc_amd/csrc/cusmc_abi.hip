@@ -599,7 +599,23 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
                                          count, X_out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
-  if (d > 159) return fail(CUSMC_ERANGE, "dense proposal kernels support d <= 159 (got %d); diagonal G and Q have no limit", d);
+  if (d > 128) {
+    // device image: [Q^T | G^T | m0] (one workgroup per particle, kernels/propagate.hip)
+    std::vector<double> img(2 * dd + d, 0.0);
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j) {
+        img[(size_t)j * d + i] = Q[(size_t)i * d + j];
+        if (G) img[dd + (size_t)j * d + i] = G[(size_t)i * d + j];
+      }
+    if (m0) std::copy(m0, m0 + d, img.begin() + 2 * dd);
+    if (int rc = ctx->scratch[4].reserve(img.size() * 8)) return rc;
+    if (int rc = ctx->ring.upload(ctx->scratch[4].p, img.data(), img.size() * 8, ctx->stream)) return rc;
+    const double *base = (const double *)ctx->scratch[4].p;
+    HIP_TRY(cusmc::launch_propagate_rows(kind, nu, X_prev_dev, a_dev, G ? base + dd : nullptr, base,
+                                         m0 ? base + 2 * dd : nullptr, d, scale, seed, step, domain, first, count,
+                                         X_out_dev, ctx->num_cus, ctx->stream));
+    return CUSMC_OK;
+  }
   // device image: [Q | G | m0]
   if (int rc = ctx->scratch[4].reserve((2 * dd + d) * 8)) return rc;
   if (int rc = upload_small(ctx, ctx->scratch[4], 0, Q, dd)) return rc;

@@ -147,6 +147,67 @@ hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const
   return hipGetLastError();
 }
 
+// Dense G / Q above d = 128, where the factors no longer fit the LDS of the matrix-core kernel: one
+// WORKGROUP per particle, thread j owns output component j.  The normals and the ancestor's row go
+// through LDS; QT / GT are the TRANSPOSED factors, so a wavefront reads one contiguous row segment
+// per k (coalesced, L2-resident).  Sums run over k in order, like the lane-per-particle kernel.
+// A single R-level draw at d = 256 costs one small launch here instead of one lane walking 65k FMAs.
+template <bool MVT>
+__global__ __launch_bounds__(256) void propagate_row_kernel(
+    float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
+    const double *__restrict__ GT, const double *__restrict__ QT, const double *__restrict__ m0,
+    int d, double scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t domain, uint32_t first,
+    uint32_t count, double *__restrict__ X_out)
+{
+  extern __shared__ double lds[];
+  double *sXi = lds, *sXp = lds + d + (d & 1);
+  for (uint32_t il = blockIdx.x; il < count; il += gridDim.x) {
+    const uint32_t i = first + il;
+    __syncthreads();
+    for (int pr = threadIdx.x; 2 * pr < d; pr += 256) {
+      double z0, z1;
+      normal_pair(philox4x32_10(i, (uint32_t)pr, step, domain, k0, k1), z0, z1);
+      sXi[2 * pr] = scale * z0;
+      if (2 * pr + 1 < d) sXi[2 * pr + 1] = scale * z1;
+    }
+    if (GT) {
+      const long anc = a ? (long)a[il] : (long)i;
+      for (int k = threadIdx.x; k < d; k += 256) sXp[k] = X_prev[anc * d + k];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < d; j += 256) {
+      double s = 0.0;
+      for (int k = 0; k < d; ++k) s = fma(QT[(long)k * d + j], sXi[k], s);
+      if (MVT) s = fma(s, sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu)), 0.0);
+      double m;
+      if (GT) {
+        m = 0.0;
+        for (int k = 0; k < d; ++k) m = fma(GT[(long)k * d + j], sXp[k], m);
+      } else {
+        m = m0[j];
+      }
+      X_out[(long)il * d + j] = s + m;
+    }
+  }
+}
+
+hipError_t launch_propagate_rows(int kind, float nu, const double *X_prev, const uint32_t *a,
+                                 const double *GT, const double *QT, const double *m0, int d,
+                                 double scale, uint64_t seed, uint32_t step, uint32_t domain,
+                                 uint32_t first, uint32_t count, double *X_out, int num_cus,
+                                 hipStream_t stream)
+{
+  if (count == 0) return hipSuccess;
+  long blocks = count;
+  const long cap = (long)num_cus * 8;
+  if (blocks > cap) blocks = cap;
+  const size_t lds_bytes = (size_t)2 * (d + (d & 1)) * sizeof(double);
+  auto kern = kind == CUSMC_MVT ? propagate_row_kernel<true> : propagate_row_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, nu, X_prev, a, GT, QT, m0, d,
+                     scale, (uint32_t)seed, (uint32_t)(seed >> 32), step, domain, first, count, X_out);
+  return hipGetLastError();
+}
+
 template <int T>
 static hipError_t launch_t(int kind, float nu, const double *X_prev, const uint32_t *a,
                            const double *G, const double *Q, const double *m0, int d,

@@ -82,6 +82,13 @@ hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const
                                  uint32_t first, uint32_t count, double *X_out, int num_cus,
                                  hipStream_t stream);
 
+// dense G / Q, 128 < d: one workgroup per particle; GT / QT are the transposed factors
+hipError_t launch_propagate_rows(int kind, float nu, const double *X_prev, const uint32_t *a,
+                                 const double *GT, const double *QT, const double *m0, int d,
+                                 double scale, uint64_t seed, uint32_t step, uint32_t domain,
+                                 uint32_t first, uint32_t count, double *X_out, int num_cus,
+                                 hipStream_t stream);
+
 // --- kernels/pf_step.hip : resample + propagate + reweight in one launch, d <= 8 -----------------
 bool pf_step_supported(int d);
 hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const double *X_prev,

@@ -475,50 +475,165 @@ ORACLE_API void oracle_propagate(double *Xt, const double *Xprev, const uint32_t
   }
 }
 
-/* Symmetric eigen square root Q = V sqrt(Lambda) -- src/linear_algebra.cpp:10-23.
- * Cyclic Jacobi.  Q Q^T = Sigma; column order / signs are not unique (nor are Eigen's). */
+/* Symmetric eigen square root Q = V sqrt(Lambda) -- src/linear_algebra.cpp:10-23, which calls
+ * Eigen's SelfAdjointEigenSolver: Householder tridiagonalisation + implicit QL (EISPACK tred2 /
+ * tql2 here), eigenvalues ascending as Eigen returns them.  Eigenvector signs are not defined by the
+ * reference (nor by Eigen); the convention here -- largest component positive -- makes Q
+ * reproducible.  Q Q^T = Sigma. */
 ORACLE_API void oracle_eigen_sqrt(const double *S, double *Q, int n)
 {
-  double *A = (double *)malloc(sizeof(double) * n * n);
-  double *V = (double *)malloc(sizeof(double) * n * n);
-  memcpy(A, S, sizeof(double) * n * n);
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);
-  for (int sweep = 0; sweep < 100; ++sweep) {
-    double off = 0.0;
-    for (int i = 0; i < n; ++i)
-      for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
-    if (off < 1e-300) break;
-    for (int p = 0; p < n; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        double apq = A[p * n + q];
-        if (apq == 0.0) continue;
-        double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < n; ++k) {
-          double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - s * akq;
-          A[k * n + q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {
-          double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = c * apk - s * aqk;
-          A[q * n + k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < n; ++k) {
-          double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - s * vkq;
-          V[k * n + q] = s * vkp + c * vkq;
-        }
+  double *V = (double *)malloc(sizeof(double) * n * n), *d = (double *)malloc(sizeof(double) * n), *e = (double *)malloc(sizeof(double) * n);
+  memcpy(V, S, sizeof(double) * n * n);
+#define v(i, j) V[(size_t)(j) * n + (i)] /* column-major: the O(n^3) loops walk down columns */
+  // ---- tred2: V <- orthogonal transformation to tridiagonal form; d = diagonal, e = sub-diagonal
+  for (int j = 0; j < n; ++j) d[j] = v(n - 1, j);
+  for (int i = n - 1; i > 0; --i) {
+    double scale = 0.0, h = 0.0;
+    for (int k = 0; k < i; ++k) scale += fabs(d[k]);
+    if (scale == 0.0) {
+      e[i] = d[i - 1];
+      for (int j = 0; j < i; ++j) {
+        d[j] = v(i - 1, j);
+        v(i, j) = 0.0;
+        v(j, i) = 0.0;
       }
-  }
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      double lam = A[j * n + j];
-      Q[i * n + j] = V[i * n + j] * sqrt(lam > 0.0 ? lam : 0.0);
+    } else {
+      for (int k = 0; k < i; ++k) {
+        d[k] /= scale;
+        h += d[k] * d[k];
+      }
+      double f = d[i - 1], g = sqrt(h);
+      if (f > 0) g = -g;
+      e[i] = scale * g;
+      h -= f * g;
+      d[i - 1] = f - g;
+      for (int j = 0; j < i; ++j) e[j] = 0.0;
+      for (int j = 0; j < i; ++j) {
+        f = d[j];
+        v(j, i) = f;
+        g = e[j] + v(j, j) * f;
+        for (int k = j + 1; k <= i - 1; ++k) {
+          g += v(k, j) * d[k];
+          e[k] += v(k, j) * f;
+        }
+        e[j] = g;
+      }
+      f = 0.0;
+      for (int j = 0; j < i; ++j) {
+        e[j] /= h;
+        f += e[j] * d[j];
+      }
+      const double hh = f / (h + h);
+      for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+      for (int j = 0; j < i; ++j) {
+        f = d[j];
+        g = e[j];
+        for (int k = j; k <= i - 1; ++k) v(k, j) -= (f * e[k] + g * d[k]);
+        d[j] = v(i - 1, j);
+        v(i, j) = 0.0;
+      }
     }
-  free(A); free(V);
+    d[i] = h;
+  }
+  for (int i = 0; i < n - 1; ++i) {
+    v(n - 1, i) = v(i, i);
+    v(i, i) = 1.0;
+    const double h = d[i + 1];
+    if (h != 0.0) {
+      for (int k = 0; k <= i; ++k) d[k] = v(k, i + 1) / h;
+      for (int j = 0; j <= i; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= i; ++k) g += v(k, i + 1) * v(k, j);
+        for (int k = 0; k <= i; ++k) v(k, j) -= g * d[k];
+      }
+    }
+    for (int k = 0; k <= i; ++k) v(k, i + 1) = 0.0;
+  }
+  for (int j = 0; j < n; ++j) {
+    d[j] = v(n - 1, j);
+    v(n - 1, j) = 0.0;
+  }
+  v(n - 1, n - 1) = 1.0;
+  e[0] = 0.0;
+  // ---- tql2: implicit QL on the tridiagonal matrix, rotations accumulated into V
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  double f = 0.0, tst1 = 0.0;
+  const double eps = 2.220446049250313e-16;
+  for (int l = 0; l < n; ++l) {
+    { const double cand = fabs(d[l]) + fabs(e[l]); if (cand > tst1) tst1 = cand; }
+    int m = l;
+    while (m < n) {
+      if (fabs(e[m]) <= eps * tst1) break;
+      ++m;
+    }
+    if (m > l) {
+      for (int iter = 0; iter < 200; ++iter) {
+        double g = d[l];
+        double p = (d[l + 1] - g) / (2.0 * e[l]);
+        double r = hypot(p, 1.0);
+        if (p < 0) r = -r;
+        d[l] = e[l] / (p + r);
+        d[l + 1] = e[l] * (p + r);
+        const double dl1 = d[l + 1];
+        double h = g - d[l];
+        for (int i = l + 2; i < n; ++i) d[i] -= h;
+        f += h;
+        p = d[m];
+        double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+        const double el1 = e[l + 1];
+        for (int i = m - 1; i >= l; --i) {
+          c3 = c2;
+          c2 = c;
+          s2 = s;
+          g = c * e[i];
+          h = c * p;
+          r = hypot(p, e[i]);
+          e[i + 1] = s * r;
+          s = e[i] / r;
+          c = p / r;
+          p = c * d[i] - s * g;
+          d[i + 1] = h + s * (c * g + s * d[i]);
+          for (int k = 0; k < n; ++k) {
+            h = v(k, i + 1);
+            v(k, i + 1) = s * v(k, i) + c * h;
+            v(k, i) = c * v(k, i) - s * h;
+          }
+        }
+        p = -s * s2 * c3 * el1 * e[l] / dl1;
+        e[l] = s * p;
+        d[l] = c * p;
+        if (fabs(e[l]) <= eps * tst1) break;
+      }
+    }
+    d[l] += f;
+    e[l] = 0.0;
+  }
+  // ascending eigenvalues (selection sort, stable for ties), then the sign convention
+  for (int i = 0; i < n - 1; ++i) {
+    int k = i;
+    double p = d[i];
+    for (int j = i + 1; j < n; ++j)
+      if (d[j] < p) {
+        k = j;
+        p = d[j];
+      }
+    if (k != i) {
+      d[k] = d[i];
+      d[i] = p;
+      for (int r = 0; r < n; ++r) { const double tmp = v(r, i); v(r, i) = v(r, k); v(r, k) = tmp; }
+    }
+  }
+  for (int j = 0; j < n; ++j) {
+    int im = 0;
+    for (int i = 1; i < n; ++i)
+      if (fabs(v(i, j)) > fabs(v(im, j))) im = i;
+    const double sg = v(im, j) < 0.0 ? -1.0 : 1.0;
+    const double root = d[j] > 0.0 ? sqrt(d[j]) : 0.0;
+    for (int i = 0; i < n; ++i) Q[(size_t)i * n + j] = sg * v(i, j) * root;
+  }
+#undef v
+  free(V); free(d); free(e);
 }
 
 /* MCMC() time loop -- src/mcmc.cpp:239-309, loop :292-308, with initialize() in front as

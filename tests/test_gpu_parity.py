@@ -402,7 +402,7 @@ def test_resampler_full_size_properties(cs):
 
 # --- draws and the filter ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("d", [2, 5, 8, 16, 33, 64, 81, 100, 128])
+@pytest.mark.parametrize("d", [2, 5, 8, 16, 33, 64, 81, 100, 128, 160, 256])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 5.0), ("mvt", 1.5)])
 def test_draws_match_oracle(cs, oracle, d, dist, nu):
     """Same Philox counters, same transform: the draws agree to rounding (libm vs ocml log/
@@ -490,13 +490,13 @@ def test_propagate_diagonal_models(cs, oracle, d, dist, nu):
 
 @pytest.mark.parametrize("seed", range(4))
 def test_propagate_random_shapes(cs, oracle, seed):
-    """Dispatch fuzz for the proposal draws: random d in [1, 159], dense or diagonal G and Q, MVN or
+    """Dispatch fuzz for the proposal draws: random d in [1, 256], dense or diagonal G and Q, MVN or
     Student-t, random shard, with and without ancestors, against the oracle's dense loops."""
     import torch
     rng = np.random.default_rng(2000 + seed)
     ctx = cs.api.default_context().use_torch_stream()
     for case in range(8):
-        d = int(rng.choice([rng.integers(1, 17), rng.integers(17, 129), rng.integers(129, 160)]))
+        d = int(rng.choice([rng.integers(1, 17), rng.integers(17, 129), rng.integers(129, 257)]))
         N = int(rng.integers(1, 1500))
         dist = str(rng.choice(["mvn", "mvt"]))
         nu = float(rng.choice([3.0, 4.0, 1.5]))
