@@ -91,12 +91,20 @@ __device__ __forceinline__ double finish(double q, const Epilogue &ep)
 //     {end, next} -- a single ds_add_rtn_u64 per tile.  Static round-robin over WAVES loses ~10 %:
 //     the older of two waves on a SIMD wins issue arbitration, finishes its share early and leaves
 //     the younger one to run alone (measured: 78 us vs 87 us wave lifetimes at d = 64).
-//   * Nothing is dynamic ACROSS workgroups.  Queueing the last eighth of the rounds (chunks of 16,
-//     then 8 tiles, drawn with scalar s_atomic_add ... glc so the drawing wave keeps its vector
-//     loads in flight -- gfx950 executes scalar atomics coherently across XCDs at ~87 per us per
-//     word, scripts/calib/satomic.hip) measured 1.0 us SLOWER than dealing everything, although
-//     workgroup lifetimes differ by ~8 % from launch to launch: a wave always has two tiles
-//     prefetched, so whoever draws last still finishes ~2 tiles after the queue runs dry.
+//   * Nothing is dynamic ACROSS workgroups, although workgroup lifetimes differ by ~8 % from launch
+//     to launch and the launch ends ~5 us after its average workgroup.  Two queued tails were built
+//     and measured against the pure deal on one box each (scripts/calib/ablate.hip):
+//       - last eighth of the rounds from ONE counter, chunks of 16 then 8 tiles, scalar
+//         s_atomic_add ... glc draws (they return through lgkmcnt, so the drawing wave keeps its
+//         vector loads in flight; gfx950 runs scalar atomics coherently across XCDs at ~87 per us
+//         per word, scripts/calib/satomic.hip), a 64-bit LDS word per tile:        +1.0 us;
+//       - last eighth from EIGHT counters (slice b % 8: ~11 draws per us per word), chunks of 8
+//         (one tile per wave) drawn a chunk ahead, dealt rounds on the unchanged cheap path:
+//         +3.7 us -- and +5.2 us with the tail compiled in but switched off at run time.  The
+//         balancing itself gains ~1.5 us; the extra paths through grab() cost the tile loop its
+//         load placement and counted waits (an s_waitcnt vmcnt(0) every second tile).
+//     A tail worth having would have to live in a loop of its own, and then pays a pipeline
+//     drain per wave at the hand-over: not pursued.
 //
 // Factor residency.  WREG (triangular, d <= 64): each lane keeps its 2*NB*(NB+1) factor values in
 // registers for the whole kernel (80 VGPRs at d = 64) -- the tile loop then has no LDS reads at
