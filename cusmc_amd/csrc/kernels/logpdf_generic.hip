@@ -77,6 +77,68 @@ __global__ __launch_bounds__(T) void logpdf_generic_kernel(
   }
 }
 
+// d < 16: one lane per particle, the row in REGISTERS (no LDS staging): D doubles per lane through
+// 16-byte loads where the row allows them, M / shift / bias through wave-uniform (scalar) loads.
+// Same operation order as the staged kernel above and as pf_step.hip, so the three agree bitwise.
+template <int D>
+__global__ __launch_bounds__(256) void logpdf_small_kernel(
+    const double *__restrict__ X, long N, long ldx, int tri, const double *__restrict__ M,
+    const double *__restrict__ shift, const double *__restrict__ bias, Epilogue ep,
+    double *__restrict__ out)
+{
+  const long stride = (long)gridDim.x * 256;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < N; i += stride) {
+    const double *row = X + i * ldx;
+    double r[D];
+    if ((D % 2 == 0) && (ldx % 2 == 0) && ((uintptr_t)X % 16 == 0)) {  // uniform
+#pragma unroll
+      for (int k = 0; k < D; k += 2) {
+        typedef double v2 __attribute__((ext_vector_type(2)));
+        const v2 t = *reinterpret_cast<const v2 *>(row + k);
+        r[k] = t[0];
+        if (k + 1 < D) r[k + 1] = t[1];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) r[k] = row[k];
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) r[k] = r[k] - shift[k];
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const int kend = tri ? j + 1 : D;
+      double z0 = bias[j], z1 = 0.0;
+#pragma unroll
+      for (int k = 0; k + 1 < D; k += 2) {
+        if (k + 1 < kend) {
+          z0 = fma(M[j * D + k], r[k], z0);
+          z1 = fma(M[j * D + k + 1], r[k + 1], z1);
+        } else if (k < kend) {
+          z0 = fma(M[j * D + k], r[k], z0);
+        }
+      }
+      if ((D & 1) && D - 1 < kend) z0 = fma(M[j * D + D - 1], r[D - 1], z0);
+      const double z = z0 + z1;
+      q = fma(z, z, q);
+    }
+    out[i] = finish_generic(q, ep);
+  }
+}
+
+template <int D>
+static hipError_t launch_small(const double *X, int64_t N, int64_t ldx, bool tri, const double *M,
+                               const double *shift, const double *bias, const Epilogue &ep, double *out,
+                               int num_cus, hipStream_t stream)
+{
+  long blocks = (N + 255) / 256;
+  const long cap = (long)num_cus * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(logpdf_small_kernel<D>, dim3((unsigned)blocks), dim3(256), 0, stream, X, (long)N, (long)ldx,
+                     (int)tri, M, shift, bias, ep, out);
+  return hipGetLastError();
+}
+
 bool generic_supported(int d) { return d >= 1 && (size_t)64 * (d | 1) * 8 <= 160 * 1024; }
 
 template <int T>
@@ -108,6 +170,14 @@ hipError_t launch_logpdf_generic(const double *X, int64_t N, int64_t ldx, int d,
 {
   if (N <= 0) return hipSuccess;
   if (!generic_supported(d)) return hipErrorInvalidValue;
+#define CUSMC_SMALL(D) case D: return launch_small<D>(X, N, ldx, tri, M, shift, bias, ep, out, num_cus, stream);
+  switch (d) {
+    CUSMC_SMALL(1) CUSMC_SMALL(2) CUSMC_SMALL(3) CUSMC_SMALL(4) CUSMC_SMALL(5) CUSMC_SMALL(6) CUSMC_SMALL(7)
+    CUSMC_SMALL(8) CUSMC_SMALL(9) CUSMC_SMALL(10) CUSMC_SMALL(11) CUSMC_SMALL(12) CUSMC_SMALL(13)
+    CUSMC_SMALL(14) CUSMC_SMALL(15)
+    default: break;
+  }
+#undef CUSMC_SMALL
   const size_t row_bytes = (size_t)(d | 1) * 8;
   if (256 * row_bytes <= 64 * 1024)
     return launch_t<256>(X, N, ldx, d, tri, M, shift, bias, ep, out, num_cus, stream);

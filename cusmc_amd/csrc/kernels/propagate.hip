@@ -208,6 +208,66 @@ hipError_t launch_propagate_rows(int kind, float nu, const double *X_prev, const
   return hipGetLastError();
 }
 
+// Dense G / Q below d = 16: one lane per particle with everything in registers (the row gather is
+// D loads, the factors come through wave-uniform scalar loads).  Operation order of propagate_kernel
+// and pf_step.hip.
+template <int D, bool MVT>
+__global__ __launch_bounds__(256) void propagate_small_kernel(
+    float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
+    const double *__restrict__ G, const double *__restrict__ Q, const double *__restrict__ m0,
+    double scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t domain, uint32_t first,
+    uint32_t count, double *__restrict__ X_out)
+{
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < count; t += stride) {
+    const uint32_t i = first + t;
+    double xp[D], xi[D];
+    if (G) {
+      const long anc = a ? (long)a[t] : (long)i;
+#pragma unroll
+      for (int k = 0; k < D; ++k) xp[k] = X_prev[anc * D + k];
+    }
+#pragma unroll
+    for (int j = 0; j < D; j += 2) {
+      double z0, z1;
+      normal_pair(philox4x32_10(i, (uint32_t)(j >> 1), step, domain, k0, k1), z0, z1);
+      xi[j] = scale * z0;
+      if (j + 1 < D) xi[j + 1] = scale * z1;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fma(Q[j * D + k], xi[k], s);
+      if (MVT) s = fma(s, sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu)), 0.0);
+      double m;
+      if (G) {
+        m = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) m = fma(G[j * D + k], xp[k], m);
+      } else {
+        m = m0[j];
+      }
+      X_out[(long)t * D + j] = s + m;
+    }
+  }
+}
+
+template <int D>
+static hipError_t launch_small(int kind, float nu, const double *X_prev, const uint32_t *a, const double *G,
+                               const double *Q, const double *m0, double scale, uint64_t seed, uint32_t step,
+                               uint32_t domain, uint32_t first, uint32_t count, double *X_out, int num_cus,
+                               hipStream_t stream)
+{
+  long blocks = ((long)count + 255) / 256;
+  const long cap = (long)num_cus * 8;
+  if (blocks > cap) blocks = cap;
+  auto kern = kind == CUSMC_MVT ? propagate_small_kernel<D, true> : propagate_small_kernel<D, false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, nu, X_prev, a, G, Q, m0, scale,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), step, domain, first, count, X_out);
+  return hipGetLastError();
+}
+
 template <int T>
 static hipError_t launch_t(int kind, float nu, const double *X_prev, const uint32_t *a,
                            const double *G, const double *Q, const double *m0, int d,
@@ -241,6 +301,15 @@ hipError_t launch_propagate(int kind, float nu, const double *X_prev, const uint
                             hipStream_t stream)
 {
   if (count == 0) return hipSuccess;
+#define CUSMC_SMALL(D) \
+  case D: return launch_small<D>(kind, nu, X_prev, a, G, Q, m0, scale, seed, step, domain, first, count, X_out, num_cus, stream);
+  switch (d) {
+    CUSMC_SMALL(1) CUSMC_SMALL(2) CUSMC_SMALL(3) CUSMC_SMALL(4) CUSMC_SMALL(5) CUSMC_SMALL(6) CUSMC_SMALL(7)
+    CUSMC_SMALL(8) CUSMC_SMALL(9) CUSMC_SMALL(10) CUSMC_SMALL(11) CUSMC_SMALL(12) CUSMC_SMALL(13)
+    CUSMC_SMALL(14) CUSMC_SMALL(15)
+    default: break;
+  }
+#undef CUSMC_SMALL
   const size_t row_bytes = (size_t)2 * (d | 1) * 8;
   if (64 * row_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (256 * row_bytes <= 64 * 1024)
