@@ -117,6 +117,7 @@ struct cusmc_ctx {
   hipStream_t stream = nullptr;
   DevBuf scratch[6];  // host-pointer entry points: X, out, w, a, small matrices
   StagingRing ring;  // pinned staging for small parameter uploads
+  DevBuf whi;        // high words of the weight vector (resampler, large N)
 };
 
 struct cusmc_dist {
@@ -355,6 +356,7 @@ CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &b : ctx->scratch) b.release();
+  ctx->whi.release();
   ctx->ring.release();
   delete ctx;
   return CUSMC_OK;
@@ -520,7 +522,13 @@ CUSMC_EXPORT int cusmc_metropolis_dev(cusmc_ctx *ctx, const double *w_dev, uint3
   if ((uint64_t)first + count > N) return fail(CUSMC_EINVAL, "shard [%u, %u) exceeds N = %u", first, first + count, N);
   if (count == 0) return CUSMC_OK;
   if (!w_dev || !a_dev) return fail(CUSMC_EINVAL, "null weight or ancestor pointer");
-  HIP_TRY(cusmc::launch_metropolis(w_dev, N, B, seed, step, first, count, a_dev, ctx->num_cus, ctx->stream));
+  const uint32_t *whi = nullptr;
+  if (cusmc::metropolis_wants_hiwords(N) && B > 1) {
+    if (int rc = ctx->whi.reserve((size_t)N * 4)) return rc;
+    HIP_TRY(cusmc::launch_hiwords(w_dev, N, (uint32_t *)ctx->whi.p, ctx->num_cus, ctx->stream));
+    whi = (const uint32_t *)ctx->whi.p;
+  }
+  HIP_TRY(cusmc::launch_metropolis(w_dev, whi, N, B, seed, step, first, count, a_dev, ctx->num_cus, ctx->stream));
   return CUSMC_OK;
 }
 
@@ -533,8 +541,9 @@ CUSMC_EXPORT int cusmc_metropolis_host(cusmc_ctx *ctx, const double *w, uint32_t
   if (int rc = ctx->scratch[2].reserve((size_t)N * 8)) return rc;
   if (int rc = ctx->scratch[3].reserve((size_t)N * 4)) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->scratch[2].p, w, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(cusmc::launch_metropolis((const double *)ctx->scratch[2].p, N, B, seed, step, 0, N,
-                                   (uint32_t *)ctx->scratch[3].p, ctx->num_cus, ctx->stream));
+  if (int rc = cusmc_metropolis_dev(ctx, (const double *)ctx->scratch[2].p, N, B, seed, step, 0, N,
+                                    (uint32_t *)ctx->scratch[3].p))
+    return rc;
   HIP_TRY(hipMemcpyAsync(a, ctx->scratch[3].p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return CUSMC_OK;
@@ -711,7 +720,13 @@ CUSMC_EXPORT int cusmc_pf_step_dev(cusmc_dist *obs, int kind, float nu, const do
   if (int rc = upload_small(ctx, ctx->scratch[4], 0, Q, dd)) return rc;
   if (int rc = upload_small(ctx, ctx->scratch[4], dd, G, dd)) return rc;
   const double *base = (const double *)ctx->scratch[4].p;
-  HIP_TRY(cusmc::launch_pf_step(kind, nu, w_prev_dev, X_prev_dev, N, d, B, base + dd, base, scale, obs->plan_tri,
+  const uint32_t *whi = nullptr;
+  if (cusmc::metropolis_wants_hiwords(N) && B > 1) {
+    if (int rc = ctx->whi.reserve((size_t)N * 4)) return rc;
+    HIP_TRY(cusmc::launch_hiwords(w_prev_dev, N, (uint32_t *)ctx->whi.p, ctx->num_cus, ctx->stream));
+    whi = (const uint32_t *)ctx->whi.p;
+  }
+  HIP_TRY(cusmc::launch_pf_step(kind, nu, w_prev_dev, whi, X_prev_dev, N, d, B, base + dd, base, scale, obs->plan_tri,
                                 (const double *)obs->Mdev.p, (const double *)obs->shift.p,
                                 (const double *)obs->bias.p, make_epilogue(obs, flags), seed, step, first,
                                 count, a_out_dev, X_out_dev, w_out_dev, ctx->num_cus, ctx->stream));

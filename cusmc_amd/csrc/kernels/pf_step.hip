@@ -6,7 +6,8 @@
 //     reweight_G(...)                                      src/mcmc.cpp:162-237
 // i.e. "the weight/resample step of the particle filter".  Given w_{t-1} and x_{t-1} complete,
 // everything about particle i of step t is independent of every other particle:
-//     a_i  = Metropolis chain i over w_{t-1}                       (B random 8-byte gathers)
+//     a_i  = Metropolis chain i over w_{t-1}                       (B random gathers; from the 4-byte
+//                                                                   high-word table once N is large: smallops.h)
 //     x_i  = G x_{t-1}[a_i] + [diag(c_i)] Q (scale * xi_i)         (one d-row gather)
 //     w_i  = pdf_{0,V}(y_t - F x_i)
 // so one lane carries one particle through all three, x_i never leaves registers between the
@@ -24,9 +25,10 @@
 
 namespace cusmc {
 
-template <int D, bool MVT>
+template <int D, bool MVT, bool HI>
 __global__ __launch_bounds__(256) void pf_step_kernel(
-    float nu, const double *__restrict__ w_prev, const double *__restrict__ X_prev,
+    float nu, const double *__restrict__ w_prev, const uint32_t *__restrict__ w_prev_hi,
+    const double *__restrict__ X_prev,
     uint32_t N, uint32_t B, const double *__restrict__ G, const double *__restrict__ Q,
     double scale, int tri, const double *__restrict__ M, const double *__restrict__ shift,
     const double *__restrict__ bias, Epilogue ep, uint32_t k0, uint32_t k1, uint32_t step,
@@ -37,7 +39,8 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
     const uint32_t i = first + t;
     // resample
-    const uint32_t anc = metropolis_chain(w_prev, N, B, i, step, k0, k1);
+    const uint32_t anc = HI ? metropolis_chain_hi(w_prev, w_prev_hi, N, B, i, step, k0, k1)
+                            : metropolis_chain(w_prev, N, B, i, step, k0, k1);
     a_out[t] = anc;
     // propagate (operation order of propagate_kernel)
     double xp[D], xi[D], x[D];
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
 
 bool pf_step_supported(int d) { return d >= 1 && d <= 8; }
 
-hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const double *X_prev,
+hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const uint32_t *w_prev_hi,
+                          const double *X_prev,
                           uint32_t N, int d, uint32_t B, const double *G, const double *Q,
                           double scale, bool tri, const double *M, const double *shift,
                           const double *bias, const Epilogue &ep, uint64_t seed, uint32_t step,
@@ -104,9 +108,10 @@ hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const double
   if (blocks > cap) blocks = cap;
 #define CUSMC_PF(D)                                                                                \
   case D: {                                                                                        \
-    auto kern = kind == CUSMC_MVT ? pf_step_kernel<D, true> : pf_step_kernel<D, false>;            \
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, nu, w_prev, X_prev, N,  \
-                       B, G, Q, scale, (int)tri, M, shift, bias, ep, (uint32_t)seed,               \
+    auto kern = kind == CUSMC_MVT ? (w_prev_hi ? pf_step_kernel<D, true, true> : pf_step_kernel<D, true, false>)   \
+                                  : (w_prev_hi ? pf_step_kernel<D, false, true> : pf_step_kernel<D, false, false>); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, nu, w_prev, w_prev_hi,  \
+                       X_prev, N, B, G, Q, scale, (int)tri, M, shift, bias, ep, (uint32_t)seed,    \
                        (uint32_t)(seed >> 32), step, first, count, a_out, X_out, w_out);           \
     break;                                                                                         \
   }

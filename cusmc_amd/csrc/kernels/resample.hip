@@ -30,11 +30,53 @@ __global__ __launch_bounds__(256) void metropolis_kernel(const double *__restric
   }
 }
 
-hipError_t launch_metropolis(const double *w, uint32_t N, uint32_t B, uint64_t seed,
+__global__ __launch_bounds__(256) void metropolis_hi_kernel(const double *__restrict__ w,
+                                                            const uint32_t *__restrict__ whi, uint32_t N,
+                                                            uint32_t B, uint32_t k0, uint32_t k1,
+                                                            uint32_t step, uint32_t first,
+                                                            uint32_t count, uint32_t *__restrict__ a)
+{
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
+    a[t] = metropolis_chain_hi(w, whi, N, B, first + t, step, k0, k1);
+  }
+}
+
+// whi[i] = high word of w[i]
+__global__ __launch_bounds__(256) void hiword_kernel(const double *__restrict__ w, uint32_t N,
+                                                     uint32_t *__restrict__ whi)
+{
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < N; i += gridDim.x * 256u)
+    whi[i] = (uint32_t)(__builtin_bit_cast(uint64_t, w[i]) >> 32);
+}
+
+// The truncated-table chain pays off once the doubles no longer fit one XCD's L2 (4 MB).
+bool metropolis_wants_hiwords(uint32_t N) { return (uint64_t)N * 8 > (3u << 20); }
+
+hipError_t launch_hiwords(const double *w, uint32_t N, uint32_t *whi, int num_cus, hipStream_t stream)
+{
+  if (N == 0) return hipSuccess;
+  long blocks = ((long)N + 255) / 256;
+  const long cap = (long)num_cus * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(hiword_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, N, whi);
+  return hipGetLastError();
+}
+
+// whi == NULL: gathers from the doubles themselves.
+hipError_t launch_metropolis(const double *w, const uint32_t *whi, uint32_t N, uint32_t B, uint64_t seed,
                              uint32_t step, uint32_t first, uint32_t count, uint32_t *a,
                              int num_cus, hipStream_t stream)
 {
   if (count == 0) return hipSuccess;
+  if (whi) {
+    long blocks = ((long)count + 255) / 256;
+    const long cap = (long)num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(metropolis_hi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, whi, N, B,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), step, first, count, a);
+    return hipGetLastError();
+  }
   long blocks = ((long)count + 255) / 256;
   const long cap = (long)num_cus * 8;
   if (blocks > cap) blocks = cap;

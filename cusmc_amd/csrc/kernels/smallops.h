@@ -159,6 +159,77 @@ static __device__ __forceinline__ uint32_t metropolis_chain(const double *__rest
   return k;
 }
 
+// The same chain with its gathers served from a table HALF the size: whi[j] = the high 32 bits of
+// w[j] (sign, exponent, 20 mantissa bits: a lower bound of w[j] within 2^-20).  At N = 1e6 the
+// doubles are 8 MB -- twice one XCD's 4 MB L2 -- and the chain is bound by L2 misses (85 us for
+// B = 10); the 4 MB table fits and the same gathers take 45 us (scripts/calib/gather_probe.hip).
+// The truncated values decide every step whose outcome they CAN decide:
+//     wj in [a, a(1+2^-20)), wk in [b, b(1+2^-20))   =>   wj/wk in ( (a/b)(1-2^-19), (a/b)(1+2^-19) )
+//     u b <= a (1 - 2^-18)  =>  u <= fl(wj / wk): accept;    u b > a (1 + 2^-18)  =>  reject
+// (margins 2x wider than needed cover every rounding in sight), and only the sliver in between --
+// about 2^-17 of the steps -- or operands outside the comfortable range (zero, denormal, tiny, huge,
+// negative, NaN) fetch the two doubles and run the reference's own test, u <= w[j] / w[k].  The
+// index sequence is therefore IDENTICAL to metropolis_chain's, and the common step saves the fp64
+// division as well.
+static __device__ __forceinline__ double hi_to_double(uint32_t hi)
+{
+  return __builtin_bit_cast(double, (uint64_t)hi << 32);
+}
+// positive, normal, and far enough from both ends of the exponent range that neither u * b nor the
+// margins can overflow or lose bits: biased exponent in [123, 1923], sign clear
+static __device__ __forceinline__ bool hi_comfortable(uint32_t hi) { return ((hi >> 20) - 123u) <= 1800u; }
+
+// One step of the chain on the truncated table: (k, bh) = current index and the high word of its
+// weight; returns with them updated.
+static __device__ __forceinline__ void metropolis_step_hi(const double *__restrict__ w, double u, uint32_t j,
+                                                          uint32_t ah, uint32_t &k, uint32_t &bh)
+{
+  bool acc, decided = false;
+  if (hi_comfortable(ah) && hi_comfortable(bh)) {
+    const double a = hi_to_double(ah), p = u * hi_to_double(bh);
+    if (p <= a * (1.0 - 0x1p-18)) {
+      acc = true;
+      decided = true;
+    } else if (p > a * (1.0 + 0x1p-18)) {
+      acc = false;
+      decided = true;
+    }
+  }
+  if (!decided) acc = u <= w[j] / w[k];  // the reference's own test, on the full doubles
+  if (acc) {
+    k = j;
+    bh = ah;
+  }
+}
+
+static __device__ __forceinline__ uint32_t metropolis_chain_hi(const double *__restrict__ w,
+                                                               const uint32_t *__restrict__ whi, uint32_t N,
+                                                               uint32_t B, uint32_t i, uint32_t step,
+                                                               uint32_t k0, uint32_t k1)
+{
+  uint32_t k = i, bh = whi[i];
+  uint32_t n = 0;
+  for (; n + 4 <= B; n += 4) {
+    double u[4];
+    uint32_t j[4], ah[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 r = philox4x32_10(i, n + c, step, 1u, k0, k1);
+      u[c] = u01_53(r.x, r.y);
+      j[c] = uint_below(r.z, r.w, N);
+      ah[c] = whi[j[c]];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) metropolis_step_hi(w, u[c], j[c], ah[c], k, bh);
+  }
+  for (; n < B; ++n) {
+    const u32x4 r = philox4x32_10(i, n, step, 1u, k0, k1);
+    const uint32_t j = uint_below(r.z, r.w, N);
+    metropolis_step_hi(w, u01_53(r.x, r.y), j, whi[j], k, bh);
+  }
+  return k;
+}
+
 static __device__ __forceinline__ double finish_generic(double q, const Epilogue &ep)
 {
   double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p(q * ep.inv_nu)

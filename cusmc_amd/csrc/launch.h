@@ -54,9 +54,12 @@ hipError_t launch_logpdf_generic(const double *X, int64_t N, int64_t ldx, int d,
                                  hipStream_t stream);
 
 // --- kernels/resample.hip ------------------------------------------------------------------------
-hipError_t launch_metropolis(const double *w, uint32_t N, uint32_t B, uint64_t seed,
-                             uint32_t step, uint32_t first, uint32_t count, uint32_t *a,
-                             int num_cus, hipStream_t stream);
+bool metropolis_wants_hiwords(uint32_t N);  // weight table too big for one XCD's L2
+hipError_t launch_hiwords(const double *w, uint32_t N, uint32_t *whi, int num_cus, hipStream_t stream);
+// whi: high words of w (launch_hiwords), or NULL to gather from the doubles
+hipError_t launch_metropolis(const double *w, const uint32_t *whi, uint32_t N, uint32_t B, uint64_t seed,
+                             uint32_t step, uint32_t first, uint32_t count, uint32_t *a, int num_cus,
+                             hipStream_t stream);
 
 // --- kernels/propagate.hip -----------------------------------------------------------------------
 // X_out[i-first] = [diag(c)] Q (scale xi) + (G ? G X_prev[a ? a[i-first] : i] : m0)
@@ -91,7 +94,8 @@ hipError_t launch_propagate_rows(int kind, float nu, const double *X_prev, const
 
 // --- kernels/pf_step.hip : resample + propagate + reweight in one launch, d <= 8 -----------------
 bool pf_step_supported(int d);
-hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const double *X_prev,
+hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const uint32_t *w_prev_hi,
+                          const double *X_prev,
                           uint32_t N, int d, uint32_t B, const double *G, const double *Q,
                           double scale, bool tri, const double *M, const double *shift,
                           const double *bias, const Epilogue &ep, uint64_t seed, uint32_t step,

@@ -361,6 +361,33 @@ def test_resampler_bit_exact_oracle(cs, oracle, N, B):
     assert np.array_equal(a, oracle.metropolis(w, B, seed, step=7))
 
 
+@pytest.mark.parametrize("B,seed", [(2, 1), (10, 99), (37, 12345678901234567)])
+@pytest.mark.parametrize("kind", ["densities", "adversarial"])
+def test_resampler_large_N_truncated_table(cs, oracle, kind, B, seed):
+    """N = 1e6 (the weight vector no longer fits one XCD's L2): the chain gathers from the table of
+    high words and settles undecidable steps with the exact test -- ancestors must still be
+    bit-identical to the oracle's plain chain.  'adversarial' plants what the shortcut must not
+    decide by itself: runs of equal weights (ratio exactly 1), ratios a hair from every u-independent
+    boundary, zeros, denormals, huge values, negatives, NaN."""
+    N = 1_000_000 if B == 10 else 450_000
+    rng = np.random.default_rng(42 + B)
+    if kind == "densities":
+        w = np.exp(-0.5 * rng.chisquare(32, N)) * 1e-20
+    else:
+        w = rng.random(N)
+        w[::7] = 0.5                                   # ties
+        w[1::7] = 0.5 * (1 + rng.integers(-4, 5, len(w[1::7])) * 2.0 ** -21)   # inside the truncation error
+        w[2::1001] = 0.0
+        w[3::1001] = 5e-324
+        w[4::1001] = 1e-310
+        w[5::1001] = 1e300
+        w[6::1001] = -0.25
+        w[7::5003] = np.nan
+        w[8::5003] = np.inf
+    a = cs.Sampler.metropolis_hastings(w, N, t=3, B=B, seed=seed)
+    assert np.array_equal(a, oracle.metropolis(w, B, seed, step=3))
+
+
 def test_resampler_shards_compose(cs, oracle):
     """Chains [first, first+count) computed separately equal the single launch (global Philox
     indices): what the multi-GPU path relies on."""
@@ -609,6 +636,35 @@ def test_fused_step_equals_three_launches(cs, d, dist, nu, general_F, diag_model
         assert torch.equal(a1, a2)
         assert torch.equal(X1, X2)
         assert torch.equal(w1, w2)
+    obs.close()
+
+
+def test_fused_step_large_N(cs, oracle):
+    """The fused step at N = 6e5 (resampling chain on the truncated weight table): ancestors equal the
+    oracle's plain chain over the same weights, states and weights equal the three separate launches."""
+    import torch
+    from cusmc_amd import api
+    N, d, B, seed, step = 600_000, 2, 10, 5, 4
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Xp = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+    wp = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) ** 8 * 1e-30
+    wp[::11] = 0.0
+    I = np.eye(d)
+    obs = cs.MultiVariateNormalDistribution(None, 0.5 * I)
+    obs.ctx.use_torch_stream()
+    a1 = torch.empty(N, dtype=torch.int32, device="cuda")
+    X1 = torch.empty(N, d, dtype=torch.float64, device="cuda")
+    w1 = torch.empty(N, dtype=torch.float64, device="cuda")
+    y = np.array([0.1, -0.2])
+    api.pf_step_dev(obs, wp, Xp, 0.9 * I, 0.3 * I, y, I, a1, X1, w1, B=B, seed=seed, step=step)
+    a2 = torch.empty_like(a1); X2 = torch.empty_like(X1); w2 = torch.empty_like(w1)
+    cs.Sampler.metropolis_hastings_dev(wp, a2, B=B, t=step, seed=seed, ctx=obs.ctx)
+    api.propagate_dev(Xp, a2, 0.9 * I, 0.3 * I, X2, "mvn", 0.0, 1.0, seed=seed, step=step, ctx=obs.ctx)
+    obs.reweight_dev(X2, y, I, w2, log=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(X1, X2) and torch.equal(w1, w2)
+    want = oracle.metropolis(wp.cpu().numpy(), B, seed, step=step)
+    assert np.array_equal(a1.cpu().numpy().astype(np.uint32), want)
     obs.close()
 
 
