@@ -136,7 +136,7 @@ __host__ __device__ constexpr bool mfma_factor_in_regs()
   return TRI && NB <= 4;
 #endif
 }
-template <int NB, bool SHIFT>
+template <int NB, bool SHIFT, bool LOGMVN>
 __host__ __device__ constexpr int mfma_sets()  // operand register sets in rotation
 {
 #ifdef EXP_SETS
@@ -149,7 +149,9 @@ __host__ __device__ constexpr int mfma_sets()  // operand register sets in rotat
   // locality.  The shifted form at d >= 48 is the exception (92.6 vs 98.7 us at d = 48): its
   // per-step subtractions lengthen a tile enough for the deeper prefetch to pay.  d >= 96 has no
   // registers for a third set.
-  return SHIFT && (NB == 3 || NB == 4) ? 3 : 2;
+  // With the run-time epilogue on top (Student-t, densities) three sets plus the hoisted shift values
+  // spill at d = 64 (128 us instead of 107), so those stay at two.
+  return SHIFT && LOGMVN && (NB == 3 || NB == 4) ? 3 : 2;
 #endif
 }
 
@@ -268,6 +270,15 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     for (int f = 0; f < NFRAG; ++f) wreg[f] = frags[f * 64 + lane];
   }
   __syncthreads();
+  // the shift values a lane subtracts are the same for every tile: 4*NB registers instead of
+  // 4*NB LDS reads per tile (d <= 64; above that the registers are spoken for)
+  double shreg[(SHIFT && WREG) ? NB : 1][4];
+  if constexpr (SHIFT && WREG) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) shreg[kb][s4] = sShift[16 * kb + pi_k(s4, h)];
+  }
   // (!WREG) the factor fragments are loop-invariant LDS reads; left alone, hipcc hoists all of
   // them out of the tile loop into spilled registers.  An opaque per-tile lane offset keeps them
   // as in-loop ds_read_b64.
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           double a = a_in[kb][s >> 1][s & 1];
-          if (SHIFT) a -= sShift[16 * kb + pi_k(s, h)];
+          if (SHIFT) a -= shreg[kb][s];
 #pragma unroll
           for (int cb = kb; cb < NB; ++cb, ++f) {
             if (ABL == 2)
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
 
   unsigned k0 = grab();
   if (k0 < nt) {
-    if constexpr (mfma_sets<NB, SHIFT>() == 3) {
+    if constexpr (mfma_sets<NB, SHIFT, LOGMVN>() == 3) {
       // Three register sets in rotation: while one tile runs on the matrix cores the loads of
       // the next TWO are in flight (16 KB per wave).  No register copies: the loop is unrolled
       // by three with the roles renamed.
