@@ -282,7 +282,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic["hbm_bytes"],
                          "algorithmic_bytes_per_launch": N_PER_GPU * ALGO_BYTES_PER_EVAL,
-                         "kernel": "cusmc::logpdf_mfma_kernel<4, true, false, 0, true>", "kernel_ms": kernel_ms,
+                         "kernel": "cusmc::logpdf_mfma_kernel<4, true, false, 0, 1, false>", "kernel_ms": kernel_ms,
                          "frac_of_measured_copy_peak": achieved / 6290.0},
             "cpu_baseline": cpu,
             "mh_steps_per_s": None if mh is None else mh.get("steps_per_s"),

@@ -34,7 +34,7 @@ void mfma_pack_frags(const double *M, int d, bool tri, double *frags)
         }
 }
 
-template <int NB, bool TRI, bool SHIFT, bool LOGMVN, bool PAD>
+template <int NB, bool TRI, bool SHIFT, int EPI, bool PAD>
 static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, int d, const double *frags,
                             const double *shift, const double *bias, const Epilogue &ep,
                             double *out, int num_cus, hipStream_t stream)
@@ -44,7 +44,7 @@ static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, int d, cons
   constexpr int THREADS = mfma_threads<NB>();
   const size_t lds_bytes = (size_t)(32 * NB + 4 + (WREG ? 0 : NFRAG * 64)) * sizeof(double);
   const long num_tiles = (N + 15) / 16;
-  auto kern = logpdf_mfma_kernel<NB, TRI, SHIFT, 0, LOGMVN, PAD>;
+  auto kern = logpdf_mfma_kernel<NB, TRI, SHIFT, 0, EPI, PAD>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -65,12 +65,12 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
                               hipStream_t stream)
 {
   if (N <= 0) return hipSuccess;
-  const bool logmvn = ep.kind == CUSMC_MVN && !ep.out_density;
+  const int epi = ep.out_density ? 0 : ep.kind == CUSMC_MVN ? 1 : 2;
   const bool pad = mfma_needs_pad(d, X, ldx);
 #define CUSMC_PADV(nb, t, s, l)                                                                   \
   (pad ? launch_nb<nb, t, s, l, true>(X, N, ldx, d, frags, shift, bias, ep, out, num_cus, stream) \
        : launch_nb<nb, t, s, l, false>(X, N, ldx, d, frags, shift, bias, ep, out, num_cus, stream))
-#define CUSMC_EPI(nb, t, s) (logmvn ? CUSMC_PADV(nb, t, s, true) : CUSMC_PADV(nb, t, s, false))
+#define CUSMC_EPI(nb, t, s) (epi == 1 ? CUSMC_PADV(nb, t, s, 1) : epi == 2 ? CUSMC_PADV(nb, t, s, 2) : CUSMC_PADV(nb, t, s, 0))
 #define CUSMC_CASE(nb)                                                                            \
   case nb:                                                                                        \
     if (!tri) return CUSMC_EPI(nb, false, false);                                                 \

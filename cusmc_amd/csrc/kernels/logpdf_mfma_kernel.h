@@ -33,8 +33,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "../launch.h"
-#include "../../../include/cusmc_hip.h"
+#include "smallops.h"
 
 namespace cusmc {
 
@@ -51,10 +50,30 @@ __device__ __forceinline__ double finish(double q, const Epilogue &ep)
   return ep.out_density ? exp(lp) : lp;
 }
 
+// log1p(t) for t >= 0 (q / nu): ln(1 + t) plus the first-order correction for the rounding of
+// 1 + t; Inf and NaN pass through.
+__device__ __forceinline__ double log1p_nonneg(double t)
+{
+  const double u = 1.0 + t;
+  const double c = (t - (u - 1.0)) * __builtin_amdgcn_rcp(u);
+  const double r = ln_pos(u) + c;
+  return u < __builtin_inf() ? r : u;
+}
+
+template <int EPI>
+__device__ __forceinline__ double finish_epi(double q, const Epilogue &ep)
+{
+  if (EPI == 1) return ep.lognorm - 0.5 * q;
+  if (EPI == 2) return ep.lognorm - ep.half_nu_plus_d * log1p_nonneg(q * ep.inv_nu);
+  return finish(q, ep);
+}
+
 // TRI  = centred form:  z = W (x - shift), W lower triangular, no bias      (pdf(y, F))
 // !TRI = affine form:   z = bias + M x,    M dense, no shift                (reweight_G)
 // SHIFT = false drops the subtraction when the shift vector is all zeros.
-// LOGMVN = true fixes the epilogue to the MVN log-density (lognorm - q/2) at compile time: the
+// EPI fixes the epilogue at compile time: 1 = MVN log-density (lognorm - q/2), 2 = Student-t
+// log-density (lognorm - (nu+d)/2 log1p(q/nu), log1p through the library's own ln: smallops.h),
+// 0 = decided at run time (densities: exp on top).  The
 // run-time epilogue (Student-t log1p, optional exp) costs ~30 VGPRs of polynomial constants that
 // stay live across the tile loop, and at d = 64 the loop owns the whole register file (80 factor +
 // 96 operand + 32 accumulator VGPRs) -- with them hipcc spilled one operand pair and drained
@@ -136,7 +155,7 @@ __host__ __device__ constexpr bool mfma_factor_in_regs()
   return TRI && NB <= 4;
 #endif
 }
-template <int NB, bool SHIFT, bool LOGMVN>
+template <int NB, bool SHIFT, int EPI>
 __host__ __device__ constexpr int mfma_sets()  // operand register sets in rotation
 {
 #ifdef EXP_SETS
@@ -151,11 +170,11 @@ __host__ __device__ constexpr int mfma_sets()  // operand register sets in rotat
   // registers for a third set.
   // With the run-time epilogue on top (Student-t, densities) three sets plus the hoisted shift values
   // spill at d = 64 (128 us instead of 107), so those stay at two.
-  return SHIFT && LOGMVN && (NB == 3 || NB == 4) ? 3 : 2;
+  return SHIFT && EPI == 1 && (NB == 3 || NB == 4) ? 3 : 2;
 #endif
 }
 
-template <int NB, bool TRI, bool SHIFT, int ABL = 0, bool LOGMVN = false, bool PAD = false>
+template <int NB, bool TRI, bool SHIFT, int ABL = 0, int EPI = 0, bool PAD = false>
 __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     const double *__restrict__ X, long N, long ldx, const double *__restrict__ frags,
     const double *__restrict__ shift, const double *__restrict__ bias, Epilogue ep,
@@ -359,7 +378,7 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
       q += __shfl_xor(q, 32);
     }
     // lanes 0..15: particles 0..15 of the tile, one 128-byte line
-    if (lane < (t == last ? (int)tail_rows : 16)) out[t * 16 + lane] = LOGMVN ? ep.lognorm - 0.5 * q : finish(q, ep);
+    if (lane < (t == last ? (int)tail_rows : 16)) out[t * 16 + lane] = finish_epi<EPI>(q, ep);
   };
 
   // ABL == 4 (diagnostic build only): shader-clock and 100 MHz wall stamps per wave, written past
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
 
   unsigned k0 = grab();
   if (k0 < nt) {
-    if constexpr (mfma_sets<NB, SHIFT, LOGMVN>() == 3) {
+    if constexpr (mfma_sets<NB, SHIFT, EPI>() == 3) {
       // Three register sets in rotation: while one tile runs on the matrix cores the loads of
       // the next TWO are in flight (16 KB per wave).  No register copies: the loop is unrolled
       // by three with the roles renamed.

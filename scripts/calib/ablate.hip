@@ -29,11 +29,11 @@ static float run(const double *X, long N, const double *frags, const double *shi
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL, true>), dim3(blocks), dim3(KT), KLDS, 0, X, N, 64L, frags, shift, bias, ep, out, tiles);
+    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL, 1>), dim3(blocks), dim3(KT), KLDS, 0, X, N, 64L, frags, shift, bias, ep, out, tiles);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
   for (int i = 0; i < reps; ++i)
-    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL, true>), dim3(blocks), dim3(KT), KLDS, 0, X, N, 64L, frags, shift, bias, ep, out, tiles);
+    hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, ABL, 1>), dim3(blocks), dim3(KT), KLDS, 0, X, N, 64L, frags, shift, bias, ep, out, tiles);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   return ms / reps * 1e3f;
@@ -69,7 +69,7 @@ int main(int argc, char **argv)
     Epilogue ep{-10.0, 0, 0, 0, 0};
       const long tiles = (N + 15) / 16;
     int occ = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, logpdf_mfma_kernel<4, true, false, 0, true>, KT, KLDS);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, logpdf_mfma_kernel<4, true, false, 0, 1>, KT, KLDS);
     printf("occupancy API (512-thread blocks): %d blocks/CU\n", occ);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int blocks : {256}) {
@@ -77,7 +77,7 @@ int main(int argc, char **argv)
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
         for (int i = 0; i < reps; ++i)
-          hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0, true>), dim3(blocks), dim3(KT), KLDS, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+          hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0, 1>), dim3(blocks), dim3(KT), KLDS, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         printf("blocks %d, %4d back-to-back launches: %.1f us each\n", blocks, reps, ms / reps * 1e3);
@@ -87,7 +87,7 @@ int main(int argc, char **argv)
         (void)hipDeviceSynchronize();
         struct timespec ts = {0, 3000000}; nanosleep(&ts, nullptr);
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0, true>), dim3(blocks), dim3(KT), KLDS, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+        hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 0, 1>), dim3(blocks), dim3(KT), KLDS, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1); tot += ms;
       }
@@ -98,8 +98,8 @@ int main(int argc, char **argv)
     Epilogue ep{-10.0, 0, 0, 0, 0};
       const long tiles = (N + 15) / 16;
     for (int i = 0; i < 300; ++i)
-      if (mode == 0) hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 4, true>), dim3(256), dim3(KT), KLDS, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
-      else hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 5, true>), dim3(256), dim3(KT), KLDS, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+      if (mode == 0) hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 4, 1>), dim3(256), dim3(KT), KLDS, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+      else hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 5, 1>), dim3(256), dim3(KT), KLDS, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st(3 * 2048);
     CK(hipMemcpy(st.data(), out + tiles * 16, st.size() * 8, hipMemcpyDeviceToHost));
