@@ -133,7 +133,8 @@ __device__ __forceinline__ double finish_epi(double q, const Epilogue &ep)
 // mode, same box): touching the first tiles' cache lines before the factor loads (+2.3 us: 64
 // distinct lines per instruction swamp the L1 miss queue and the factor loads sit behind them);
 // a single-exit tile loop with guarded computes, which gives textbook counted waits (+1.6 us);
-// non-temporal output stores (+0.3 us) or particle loads (+1.4 us); rotating each workgroup's slot from round to round, in case a
+// non-temporal output stores (+0.3 us) or particle loads (+1.4 us); spreading the next tile's loads
+// between the MFMAs with sched_group_barrier (+0.7 us); rotating each workgroup's slot from round to round, in case a
 // fixed slot pinned a workgroup to the same HBM channels (no effect: 94.4-95.2 us for rotations 0,
 // 1, 8, 37, 97 on one box).
 template <int NB>
