@@ -705,7 +705,11 @@ CUSMC_EXPORT int cusmc_pf_step_dev(cusmc_dist *obs, int kind, float nu, const do
   if (!w_prev_dev || !X_prev_dev || !a_out_dev || !X_out_dev || !w_out_dev)
     return fail(CUSMC_EINVAL, "null device pointer");
   const int d = obs->d;
-  if (!cusmc::pf_step_supported(d)) {
+  // One launch instead of three pays where launches are what a step costs (small shards) or where the
+  // state is a register pair (d <= 2); a big shard at d = 8 is quicker through the three specialised
+  // kernels (105 vs 120 us for 1e6 particles): the fused kernel's register footprint halves occupancy.
+  const bool fused = cusmc::pf_step_supported(d) && (d <= 2 || count <= 200000u);
+  if (!fused) {
     if (int rc = cusmc_metropolis_dev(ctx, w_prev_dev, N, B, seed, step, first, count, a_out_dev)) return rc;
     if (int rc = draws(ctx, kind, nu, X_prev_dev, a_out_dev, G, Q, nullptr, d, scale, seed, step, 2u, first, count,
                        X_out_dev))
