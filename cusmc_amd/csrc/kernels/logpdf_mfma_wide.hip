@@ -181,6 +181,11 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
           for (int t = 0; t < TILES; ++t) {
             auto *dst = (__attribute__((address_space(3))) void *)(buf + ((kb * 2 + h2) * TILES + t) * 128);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, t * tile_bytes + 128 * kb + 64 * h2, 0, 0);
+            // Pace the stream: issued as one burst, the group's 64 KB of HBM reads sit in the CU's
+            // vector-memory path in front of the compute waves' fragment loads, which then see
+            // HBM latency instead of L2 latency (full kernel 672 -> 642 us in the calibration run
+            // with ~512 idle cycles after each k-block's slabs; flat between 256 and 900).
+            if (t == TILES - 1 && h2 == 1) __builtin_amdgcn_s_sleep(8);
           }
     };
     stage_group(blockIdx.x, sX);
@@ -203,6 +208,15 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
   auto load_w = [&](int fi) -> double {  // fragment fi of this wave's stream
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, wlane, wbyte0 + fi * 512, 0));
   };
+
+  // The fragments of this wave's FIRST k-block are the same for every group: they stay in registers
+  // (16 VGPRs of the ~30 the kernel has to spare), so a group starts multiplying as soon as its rows
+  // are staged instead of waiting one L2 round trip (~4 % of a group) for them.
+  double w0[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w0[s][i] = load_w(s * 2 + i);
 
   __syncthreads();  // the first group is staged
   int parity = 0;
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) wc[s][i] = load_w(s * 2 + i);
+      for (int i = 0; i < 2; ++i) wc[s][i] = w0[s][i];
     load_x(0, xa);
 
     // one k-block with M live members (slot i = member 2 - M + i): prefetch the next k-block's
