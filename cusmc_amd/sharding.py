@@ -74,3 +74,69 @@ def gather_final(a_local, n_total, group=None):
     if dist.get_world_size(group) == 1:
         return a_local
     return all_gather_ragged(a_local, n_total, group)
+
+
+def run_filter_sharded(N, T, init_fn, step_fn, group=None):
+    """The bootstrap filter's time loop (MCMC(), src/mcmc.cpp:292-308) with the particles sharded
+    over the ranks -- the exact algorithm, not an island filter:
+
+        x_0, w_0 = init_fn(first, count)                         this rank's rows of step 0
+        for t = 1 .. T-1:
+            w_full = all-gather(w_{t-1});  X_full = all-gather(x_{t-1})
+            a_t, x_t, w_t = step_fn(t, w_full, X_full, first, count)   this rank's rows of step t
+
+    Chain i reads w_{t-1}[j] for arbitrary j and particle i reads x_{t-1}[a_i] from anywhere, so
+    both vectors are gathered whole once per step (8 N and 8 N d bytes: 8 + 16 MB at N = 1e6,
+    d = 2); everything else is local and keyed by the GLOBAL particle index, so the concatenated
+    shards equal the single-process run.  Returns this rank's (X [T, count, d], w [T, count],
+    a [T, count]) -- ancestors of step 0 are zero, as in cusmc_pf_run_host.
+
+    The compute is passed in (gpu_filter_callables() builds it over cusmc_pf_step_dev) so that the
+    CPU tests can drive the same loop with stand-ins."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    first, count = shard_range(N, rank, world)
+    x, w = init_fn(first, count)
+    if w is None:  # initialize(): w_0 = 1/N (src/mcmc.cpp:85)
+        w = torch.full((count,), 1.0 / N, dtype=torch.float64, device=x.device)
+    X_hist, w_hist, a_hist = [x], [w], [torch.zeros(count, dtype=torch.int32, device=x.device)]
+    for t in range(1, T):
+        w_full = all_gather_ragged(w, N, group) if world > 1 else w
+        X_full = all_gather_ragged(x, N, group) if world > 1 else x
+        a, x, w = step_fn(t, w_full, X_full, first, count)
+        X_hist.append(x)
+        w_hist.append(w)
+        a_hist.append(a)
+    return torch.stack(X_hist), torch.stack(w_hist), torch.stack(a_hist)
+
+
+def gpu_filter_callables(Y, m0, C0, F, G, V, W, df=0.0, distribution="mvn", B=10, seed=0, compat=False, ctx=None):
+    """init_fn / step_fn for run_filter_sharded over the HIP library on this rank's GPU: the same
+    kernels, parameters and Philox keys as cusmc_pf_run_host (cusmc_amd.run), restricted to the rows
+    [first, first + count).  Y is d x T (columns = time), as run() takes it."""
+    import numpy as np
+
+    from . import api
+    ctx = ctx or api.default_context()
+    ctx.use_torch_stream()
+    Y = np.asarray(Y, dtype=np.float64)
+    d = Y.shape[0]
+    m0, C0, F, G, V, W = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (m0, C0, F, G, V, W))
+    Q0, Qw = api.eigenSolver(C0), api.eigenSolver(W)
+    scale = api.SQRT3 if compat else 1.0
+    obs = (api.MultiVariateNormalDistribution(None, V, ctx=ctx) if distribution == "mvn"
+           else api.MultiVariateTStudentDistribution(None, V, df, ctx=ctx))
+    def init_fn(first, count):
+        x = torch.empty(count, d, dtype=torch.float64, device="cuda")
+        api.initialize_dev(m0, Q0, x, distribution, df, scale, seed=seed, first=first, ctx=ctx)
+        return x, None  # w_0 = 1/N: filled in by run_filter_sharded
+
+    def step_fn(t, w_full, X_full, first, count):
+        a = torch.empty(count, dtype=torch.int32, device="cuda")
+        x = torch.empty(count, d, dtype=torch.float64, device="cuda")
+        w = torch.empty(count, dtype=torch.float64, device="cuda")
+        api.pf_step_dev(obs, w_full, X_full, G, Qw, Y[:, t], F, a, x, w, kind=distribution, nu=df, B=B,
+                        scale=scale, seed=seed, step=t, first=first)
+        return a, x, w
+
+    return init_fn, step_fn, obs

@@ -6,7 +6,7 @@ well-conditioned covariances), ancestor indices bit-exact."""
 import numpy as np
 import pytest
 
-from conftest import DIMS, RESAMPLE_CASES, spd
+from conftest import DIMS, RESAMPLE_CASES, ROOT, spd
 
 pytestmark = pytest.mark.gpu
 
@@ -712,3 +712,51 @@ def test_cpp_host_mirror(cs):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
+
+
+def _sharded_gpu_worker(rank, world, port, N, d, T, tmp):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)  # rehearsal: both ranks on the one GPU of the test box
+    from cusmc_amd.sharding import gather_final, gpu_filter_callables, run_filter_sharded
+    I = np.eye(d)
+    Y = np.cumsum(0.1 * np.random.default_rng(5).standard_normal((d, T)), axis=1)
+    init_fn, step_fn, obs = gpu_filter_callables(Y, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, 0.0, "mvn", B=10, seed=21)
+    Xl, wl, al = run_filter_sharded(N, T, init_fn, step_fn)
+    torch.cuda.synchronize()
+    Xf = gather_final(Xl.permute(1, 0, 2).contiguous().cpu(), N).permute(1, 0, 2)
+    wf = gather_final(wl.t().contiguous().cpu(), N).t()
+    af = gather_final(al.t().contiguous().cpu(), N).t()
+    if rank == 0:
+        np.savez(tmp, X=Xf.numpy(), w=wf.numpy(), a=af.numpy(), Y=Y)
+    obs.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d", [(5003, 2), (3001, 16)])
+def test_sharded_filter_on_gpu_equals_run(cs, tmp_path, N, d):
+    """The multi-GPU filter path end to end (two ranks rehearsed on one device, gloo): shards
+    computed by cusmc_pf_step_dev with global Philox indices, weights and states all-gathered every
+    step -- the concatenated history is bitwise the single-process cusmc_pf_run_host result."""
+    import socket
+    import torch.multiprocessing as mp
+    T = 5
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tmp = str(tmp_path / "pf.npz")
+    mp.spawn(_sharded_gpu_worker, args=(2, port, N, d, T, tmp), nprocs=2, join=True)
+    got = np.load(tmp)
+    I = np.eye(d)
+    res = cs.run(N, d, T, got["Y"], np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn",
+                 seed=21, return_ancestors=True)
+    assert np.array_equal(got["a"][1:], res["ancestors"][1:].astype(got["a"].dtype))
+    assert np.array_equal(got["X"], res["posterior_x"])
+    assert np.array_equal(got["w"], res["weights"])

@@ -75,3 +75,52 @@ def test_two_rank_sharded_path_equals_single_process(tmp_path, n, oracle):
     w = np.exp(oracle.logpdf_hoisted(X, None, sigma))
     assert np.array_equal(got["lp"], w)                      # ragged all-gather is exact
     assert np.array_equal(got["a"], oracle.metropolis(w, 10, seed=77, step=2))
+
+
+def _filter_worker(rank, world, port, N, d, T, tmp):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cusmc_amd.sharding import gather_final, run_filter_sharded
+    from oracle import oracle as O
+    I = np.eye(d)
+    rng = np.random.default_rng(5)
+    Y = np.cumsum(0.1 * rng.standard_normal((T, d)), axis=0)
+    G, Qw, Q0 = 0.9 * I, O.eigen_sqrt(0.1 * I), O.eigen_sqrt(I)
+    V = 0.5 * I
+
+    def init_fn(first, count):  # stand-in: the oracle draws all N rows, this rank keeps its own
+        X0, _ = O.initialize(N, np.zeros(d), Q0, "mvn", 0.0, 1.0, seed=9, step=0)
+        return torch.from_numpy(X0[first:first + count]), None
+
+    def step_fn(t, w_full, X_full, first, count):
+        a = O.metropolis(w_full.numpy(), 10, 9, step=t)
+        X = O.propagate(X_full.numpy(), a, G, Qw, "mvn", 0.0, 1.0, seed=9, step=t)
+        w = O.reweight(X, Y[t], I, V, "mvn", 0.0)
+        sl = slice(first, first + count)
+        return (torch.from_numpy(a[sl].astype(np.int32)), torch.from_numpy(X[sl].copy()), torch.from_numpy(w[sl].copy()))
+
+    Xl, wl, al = run_filter_sharded(N, T, init_fn, step_fn)
+    # the shards are rows [first, first+count) of every step: gather along the particle axis
+    Xf = gather_final(Xl.permute(1, 0, 2).contiguous(), N).permute(1, 0, 2)
+    wf = gather_final(wl.t().contiguous(), N).t()
+    af = gather_final(al.t().contiguous(), N).t()
+    if rank == 0:
+        np.savez(tmp, X=Xf.numpy(), w=wf.numpy(), a=af.numpy(), Y=Y)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_filter_equals_single_process(tmp_path, oracle):
+    """run_filter_sharded over gloo, world_size 2, with the oracle as the per-step compute: the
+    gathered history equals the oracle's own single-process filter (same Philox keys, global
+    particle indices)."""
+    N, d, T = 203, 2, 6
+    tmp = str(tmp_path / "pf.npz")
+    mp.spawn(_filter_worker, args=(2, _free_port(), N, d, T, tmp), nprocs=2, join=True)
+    got = np.load(tmp)
+    I = np.eye(d)
+    Xo, wo, ao = oracle.pf_run(got["Y"], N, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, "mvn", 0.0, B=10, seed=9)
+    assert np.array_equal(got["a"][1:], ao[1:])
+    assert np.allclose(got["X"], Xo, atol=1e-12) and np.allclose(got["w"], wo, rtol=1e-10)
