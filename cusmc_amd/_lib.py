@@ -38,6 +38,8 @@ SYMBOLS = [
     ("cusmc_dist_reweight_host", _i, [_vp, _vp, _i64, _i64, _vp, _vp, _i, _vp]),
     ("cusmc_metropolis_dev", _i, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _vp]),
     ("cusmc_metropolis_host", _i, [_vp, _vp, _u32, _u32, _u64, _u32, _vp]),
+    ("cusmc_metropolis_log_dev", _i, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _vp]),
+    ("cusmc_metropolis_log_host", _i, [_vp, _vp, _u32, _u32, _u64, _u32, _vp]),
     ("cusmc_propagate_dev", _i, [_vp, _i, _f, _vp, _vp, _u32, _i, _vp, _vp, _d, _u64, _u32, _u32,
                                  _u32, _vp]),
     ("cusmc_initialize_dev", _i, [_vp, _i, _f, _vp, _vp, _i, _d, _u64, _u32, _u32, _vp]),

@@ -277,6 +277,27 @@ class Sampler:
         return a
 
     @staticmethod
+    def metropolis_hastings_log(logw, N=None, t=1, B=10, seed=None, ctx=None):
+        """The chain over LOG-weights (accept iff u <= exp(logw[j] - logw[k])): the resampler for
+        log-densities, which do not underflow at large d the way the reference's densities do."""
+        logw = _f64(logw).reshape(-1)
+        N = logw.shape[0] if N is None else int(N)
+        if seed is None:
+            seed, _ = _next_stream()
+        ctx = ctx or default_context()
+        a = np.empty(N, dtype=np.uint32)
+        check(_lib.lib().cusmc_metropolis_log_host(ctx._h, _ptr(logw), N, int(B), int(seed), int(t), _ptr(a)))
+        return a
+
+    @staticmethod
+    def metropolis_hastings_log_dev(logw, a, B=10, t=1, seed=0, first=0, ctx=None):
+        ctx = ctx or default_context()
+        check(_lib.lib().cusmc_metropolis_log_dev(ctx._h, C.c_void_p(logw.data_ptr()), logw.numel(), int(B),
+                                                  int(seed), int(t), int(first), a.numel(),
+                                                  C.c_void_p(a.data_ptr())))
+        return a
+
+    @staticmethod
     def metropolis_hastings_dev(w, a, B=10, t=1, seed=0, first=0, ctx=None):
         """Device-resident: w float64 CUDA tensor (all N weights), a int32/uint32-sized CUDA
         tensor receiving the ancestors of chains [first, first + len(a))."""

@@ -549,6 +549,35 @@ CUSMC_EXPORT int cusmc_metropolis_host(cusmc_ctx *ctx, const double *w, uint32_t
   return CUSMC_OK;
 }
 
+CUSMC_EXPORT int cusmc_metropolis_log_dev(cusmc_ctx *ctx, const double *logw_dev, uint32_t N, uint32_t B,
+                                          uint64_t seed, uint32_t step, uint32_t first, uint32_t count,
+                                          uint32_t *a_dev)
+{
+  if (int rc = activate(ctx)) return rc;
+  if ((uint64_t)first + count > N) return fail(CUSMC_EINVAL, "shard [%u, %u) exceeds N = %u", first, first + count, N);
+  if (count == 0) return CUSMC_OK;
+  if (!logw_dev || !a_dev) return fail(CUSMC_EINVAL, "null weight or ancestor pointer");
+  HIP_TRY(cusmc::launch_metropolis_log(logw_dev, N, B, seed, step, first, count, a_dev, ctx->num_cus, ctx->stream));
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_metropolis_log_host(cusmc_ctx *ctx, const double *logw, uint32_t N, uint32_t B,
+                                           uint64_t seed, uint32_t step, uint32_t *a)
+{
+  if (int rc = activate(ctx)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (!logw || !a) return fail(CUSMC_EINVAL, "null weight or ancestor pointer");
+  if (int rc = ctx->scratch[2].reserve((size_t)N * 8)) return rc;
+  if (int rc = ctx->scratch[3].reserve((size_t)N * 4)) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->scratch[2].p, logw, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = cusmc_metropolis_log_dev(ctx, (const double *)ctx->scratch[2].p, N, B, seed, step, 0, N,
+                                        (uint32_t *)ctx->scratch[3].p))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(a, ctx->scratch[3].p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSMC_OK;
+}
+
 // ---- proposal draws -------------------------------------------------------------------------
 
 namespace {

@@ -42,6 +42,29 @@ __global__ __launch_bounds__(256) void metropolis_hi_kernel(const double *__rest
   }
 }
 
+__global__ __launch_bounds__(256) void metropolis_log_kernel(const double *__restrict__ lw, uint32_t N,
+                                                             uint32_t B, uint32_t k0, uint32_t k1,
+                                                             uint32_t step, uint32_t first,
+                                                             uint32_t count, uint32_t *__restrict__ a)
+{
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
+    a[t] = metropolis_chain_log(lw, N, B, first + t, step, k0, k1);
+  }
+}
+
+hipError_t launch_metropolis_log(const double *lw, uint32_t N, uint32_t B, uint64_t seed, uint32_t step,
+                                 uint32_t first, uint32_t count, uint32_t *a, int num_cus, hipStream_t stream)
+{
+  if (count == 0) return hipSuccess;
+  long blocks = ((long)count + 255) / 256;
+  const long cap = (long)num_cus * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(metropolis_log_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, lw, N, B,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), step, first, count, a);
+  return hipGetLastError();
+}
+
 // whi[i] = high word of w[i]
 __global__ __launch_bounds__(256) void hiword_kernel(const double *__restrict__ w, uint32_t N,
                                                      uint32_t *__restrict__ whi)

@@ -120,7 +120,11 @@ static __device__ double chi_square_for(uint32_t particle, uint32_t j, uint32_t 
 // The draw order (u, then j), the division and the `<=` are the reference's, so a NaN ratio never
 // accepts.  The random numbers and the gather of step n do not depend on the chain state, only
 // the compare does, so the loop is unrolled by four: four Philox blocks and four gathers are in
-// flight before the four dependent accept tests.
+// flight before the four dependent accept tests.  The chain state is updated by SELECTS, not inside
+// `if (accept) { k = j; ... }`: with an accept condition of the form `a || expensive(b)` hipcc 7.2
+// (gfx950) dropped the `k = j` of the second disjunct -- the register that held j was reused for
+// expensive()'s result and `k` got its old value back while its companion (the weight) was updated --
+// caught by the bit-exact comparison with the oracle, twice.
 static __device__ __forceinline__ uint32_t metropolis_chain(const double *__restrict__ w, uint32_t N,
                                                             uint32_t B, uint32_t i, uint32_t step,
                                                             uint32_t k0, uint32_t k1)
@@ -140,10 +144,9 @@ static __device__ __forceinline__ uint32_t metropolis_chain(const double *__rest
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (u[c] <= wj[c] / wk) {
-        k = j[c];
-        wk = wj[c];
-      }
+      const bool acc = u[c] <= wj[c] / wk;
+      k = acc ? j[c] : k;
+      wk = acc ? wj[c] : wk;
     }
   }
   for (; n < B; ++n) {
@@ -151,10 +154,9 @@ static __device__ __forceinline__ uint32_t metropolis_chain(const double *__rest
     const double u = u01_53(r.x, r.y);
     const uint32_t j = uint_below(r.z, r.w, N);
     const double wj = w[j];
-    if (u <= wj / wk) {
-      k = j;
-      wk = wj;
-    }
+    const bool acc = u <= wj / wk;
+    k = acc ? j : k;
+    wk = acc ? wj : wk;
   }
   return k;
 }
@@ -196,10 +198,8 @@ static __device__ __forceinline__ void metropolis_step_hi(const double *__restri
     }
   }
   if (!decided) acc = u <= w[j] / w[k];  // the reference's own test, on the full doubles
-  if (acc) {
-    k = j;
-    bh = ah;
-  }
+  k = acc ? j : k;
+  bh = acc ? ah : bh;
 }
 
 static __device__ __forceinline__ uint32_t metropolis_chain_hi(const double *__restrict__ w,
@@ -226,6 +226,72 @@ static __device__ __forceinline__ uint32_t metropolis_chain_hi(const double *__r
     const u32x4 r = philox4x32_10(i, n, step, 1u, k0, k1);
     const uint32_t j = uint_below(r.z, r.w, N);
     metropolis_step_hi(w, u01_53(r.x, r.y), j, whi[j], k, bh);
+  }
+  return k;
+}
+
+// exp(t) for t <= 0, written so that oracle/cusmc_oracle.c:exp_nonpos evaluates the SAME sequence
+// of correctly rounded operations (explicit fma where fused, nothing else for the compiler to
+// contract): the log-weight resampler's accept test u <= exp(lw[j] - lw[k]) then gives bit-identical
+// index sequences on the GPU and in the oracle, which no pair of library exp() would.  Reduction
+// t = k ln2 + r and the degree-5 rational form of fdlibm's e_exp.c (constants from there).
+static __device__ __forceinline__ double exp_nonpos(double t)
+{
+  // branch-free: the core runs on a clamped argument and the out-of-range answers are selected in
+  // afterwards (underflow and -inf -> 0, NaN -> NaN).  Same operations as the oracle on (-746, 0].
+  const bool in_range = t > -746.0;
+  const double tc = in_range ? (t < 0.0 ? t : 0.0) : -746.0;
+  const double kf = __builtin_rint(tc * 1.44269504088896338700e+00);
+  double r = fma(-kf, 6.93147180369123816490e-01, tc);
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  const double r2 = r * r;
+  const double pp = fma(r2, fma(r2, fma(r2, fma(r2, 4.13813679705723846039e-08, -1.65339022054652515390e-06),
+                                        6.61375632143793436117e-05), -2.77777777770155933842e-03),
+                        1.66666666666666019037e-01);
+  const double c = fma(-r2, pp, r);
+  const double num = r * c;
+  const double den = c - 2.0;
+  const double quo = num / den;
+  const double e = ldexp(1.0 - (quo - r), (int)kf);
+  return in_range ? e : (t != t ? t : 0.0);
+}
+
+// The chain over LOG-weights: accept iff u <= exp(lw[j] - lw[k]); a non-negative difference accepts
+// without evaluating anything (u < 1).  -inf is a zero weight: it is never entered except from
+// another zero weight's NaN ... which rejects, as w = 0 does in the density form.
+static __device__ __forceinline__ uint32_t metropolis_chain_log(const double *__restrict__ lw, uint32_t N,
+                                                                uint32_t B, uint32_t i, uint32_t step,
+                                                                uint32_t k0, uint32_t k1)
+{
+  uint32_t k = i;
+  double lk = lw[i];
+  uint32_t n = 0;
+  for (; n + 4 <= B; n += 4) {
+    double u[4], lj[4];
+    uint32_t j[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 r = philox4x32_10(i, n + c, step, 1u, k0, k1);
+      u[c] = u01_53(r.x, r.y);
+      j[c] = uint_below(r.z, r.w, N);
+      lj[c] = lw[j[c]];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double t = lj[c] - lk;
+      const bool acc = (t >= 0.0) | (u[c] <= exp_nonpos(t));
+      k = acc ? j[c] : k;  // (selects, not branches: see the note on metropolis_chain)
+      lk = acc ? lj[c] : lk;
+    }
+  }
+  for (; n < B; ++n) {
+    const u32x4 r = philox4x32_10(i, n, step, 1u, k0, k1);
+    const double u = u01_53(r.x, r.y);
+    const uint32_t j = uint_below(r.z, r.w, N);
+    const double lj = lw[j], t = lj - lk;
+    const bool acc = (t >= 0.0) | (u <= exp_nonpos(t));
+    k = acc ? j : k;
+    lk = acc ? lj : lk;
   }
   return k;
 }

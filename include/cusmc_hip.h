@@ -117,6 +117,17 @@ int cusmc_metropolis_dev(cusmc_ctx *ctx, const double *w_dev, uint32_t N, uint32
 int cusmc_metropolis_host(cusmc_ctx *ctx, const double *w, uint32_t N, uint32_t B, uint64_t seed,
                           uint32_t step, uint32_t *a);
 
+/* The same chain over LOG-weights (what the log-density entry points produce with CUSMC_OUT_LOG):
+ *     accept  iff  u <= exp(logw[j] - logw[k])
+ * -- the reference's test with w = exp(logw), without the underflow that turns densities at large d
+ * into 0 / 0.  The reference stores densities (reweight_G, src/mcmc.cpp:208) and has no such entry;
+ * this is the lower boundary's extension named in SURVEY.md 8(b).  -inf is a zero weight. */
+int cusmc_metropolis_log_dev(cusmc_ctx *ctx, const double *logw_dev, uint32_t N, uint32_t B,
+                             uint64_t seed, uint32_t step, uint32_t first, uint32_t count,
+                             uint32_t *a_dev);
+int cusmc_metropolis_log_host(cusmc_ctx *ctx, const double *logw, uint32_t N, uint32_t B,
+                              uint64_t seed, uint32_t step, uint32_t *a);
+
 /* ---- proposal draws ------------------------------------------------------------------------
  * propagate_K -- src/mcmc.cpp:90-160 (replaces mvn_sample_kernel_wrapper /
  * mvt_sample_kernel_wrapper, mvn_dist.hpp:29-32,48-54):

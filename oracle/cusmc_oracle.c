@@ -356,6 +356,52 @@ ORACLE_API void oracle_metropolis(uint32_t *a, const double *w, uint32_t N, uint
   }
 }
 
+/* exp(t) for t <= 0 as ONE fixed sequence of correctly rounded operations (reduction t = k ln2 + r,
+ * fdlibm e_exp.c's rational form; this file is built with -ffp-contract=off), mirrored operation for
+ * operation by cusmc_amd/csrc/kernels/smallops.h:exp_nonpos -- so that the log-weight accept test is
+ * bit-identical on both sides, which libm's exp and the GPU library's would not be. */
+static double exp_nonpos(double t)
+{
+  if (!(t > -746.0)) return t != t ? t : 0.0;
+  const double kf = rint(t * 1.44269504088896338700e+00);
+  double r = fma(-kf, 6.93147180369123816490e-01, t);
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  const double r2 = r * r;
+  const double pp = fma(r2, fma(r2, fma(r2, fma(r2, 4.13813679705723846039e-08, -1.65339022054652515390e-06),
+                                        6.61375632143793436117e-05), -2.77777777770155933842e-03),
+                        1.66666666666666019037e-01);
+  const double c = fma(-r2, pp, r);
+  const double num = r * c;
+  const double den = c - 2.0;
+  const double quo = num / den;
+  const double e = 1.0 - (quo - r);
+  return ldexp(e, (int)kf);
+}
+
+/* The Metropolis chain over log-weights: the reference's test (src/samplers.cpp:27-31) with
+ * w = exp(lw), i.e. u <= exp(lw[j] - lw[k]); a non-negative difference always accepts (u < 1). */
+ORACLE_API void oracle_metropolis_log(uint32_t *a, const double *lw, uint32_t N, uint32_t B,
+                                      uint64_t seed, uint32_t step)
+{
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < N; ++i) {
+    uint32_t k = i;
+    double lk = lw[k];
+    for (uint32_t n = 0; n < B; ++n) {
+      uint32_t ctr[4] = {i, n, step, 1u}, r[4];
+      oracle_philox4x32_10(ctr, key, r);
+      double u = u01_53(r[0], r[1]);
+      uint32_t j = uint_below(r[2], r[3], N);
+      double lj = lw[j], t = lj - lk;
+      if (t >= 0.0 || u <= exp_nonpos(t)) { k = j; lk = lj; }
+    }
+    a[i] = k;
+  }
+}
+
+ORACLE_API double oracle_exp_nonpos(double t) { return exp_nonpos(t); }
+
 /* Standard-normal pair by Box-Muller from one Philox block: u1 in (0,1], u2 in [0,1). */
 static inline void normal_pair(const uint32_t r[4], double *z0, double *z1)
 {

@@ -148,6 +148,21 @@ def metropolis(w, B, seed, step=1, N=None):
     return a
 
 
+def metropolis_log(lw, B, seed, step=1):
+    """The same chain over log-weights: accept iff u <= exp(lw[j] - lw[k])."""
+    lw = _d(lw)
+    N = lw.shape[0]
+    a = np.empty(N, dtype=np.uint32)
+    lib().oracle_metropolis_log(_p(a), _p(lw), C.c_uint32(N), C.c_uint32(B), C.c_uint64(seed), C.c_uint32(step))
+    return a
+
+
+def exp_nonpos(t):
+    f = lib().oracle_exp_nonpos
+    f.restype = C.c_double
+    return f(C.c_double(t))
+
+
 def eigen_sqrt(S):
     S = _d(S)
     Q = np.empty_like(S)

@@ -388,6 +388,31 @@ def test_resampler_large_N_truncated_table(cs, oracle, kind, B, seed):
     assert np.array_equal(a, oracle.metropolis(w, B, seed, step=3))
 
 
+@pytest.mark.parametrize("N,B", [(1, 5), (63, 3), (100_000, 10), (100_000, 101), (700_000, 10)])
+def test_log_weight_resampler_bit_exact(cs, oracle, N, B):
+    """cusmc_metropolis_log: accept iff u <= exp(lw[j] - lw[k]), with exp as ONE fixed sequence of
+    rounded operations mirrored in the oracle -- so the index sequences are bit-identical, including
+    far below the density form's underflow, with -inf (zero) weights, NaN, and shard by shard."""
+    import torch
+    rng = np.random.default_rng(N + B)
+    lw = -0.5 * rng.chisquare(64, N) - 1500.0
+    if N > 100:
+        lw[::13] = -np.inf
+        lw[5::1001] = np.nan
+        lw[7::1001] = 0.0
+    seed = 0xFEED_FACE_CAFE_BEEF
+    a = cs.Sampler.metropolis_hastings_log(lw, N, t=4, B=B, seed=seed)
+    want = oracle.metropolis_log(lw, B, seed, step=4)
+    assert np.array_equal(a, want)
+    if N >= 1000:
+        lwd = torch.from_numpy(lw).cuda()
+        first, count = N // 3, N // 2
+        part = torch.empty(count, dtype=torch.int32, device="cuda")
+        cs.Sampler.metropolis_hastings_log_dev(lwd, part, B=B, t=4, seed=seed, first=first)
+        torch.cuda.synchronize()
+        assert np.array_equal(part.cpu().numpy().astype(np.uint32), want[first:first + count])
+
+
 def test_resampler_shards_compose(cs, oracle):
     """Chains [first, first+count) computed separately equal the single launch (global Philox
     indices): what the multi-GPU path relies on."""

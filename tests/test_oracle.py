@@ -186,3 +186,26 @@ def test_filter_matches_golden(oracle, golden):
         assert np.allclose(X, golden["pf_%s_X" % dist], rtol=0, atol=1e-12)
         assert np.allclose(w, golden["pf_%s_w" % dist], rtol=1e-10)
         assert np.all(a[0] == 0) and np.allclose(w[0], 1 / 64)
+
+
+def test_log_weight_resampler_restatement(oracle):
+    """oracle_metropolis_log is the density chain with w = exp(lw): identical ancestors wherever
+    no accept test sits within rounding of its boundary (all but a handful of 1e5 chains), and it keeps
+    working where the densities underflow to 0/0.  exp_nonpos agrees with libm to 2 ulp."""
+    import math
+    rng = np.random.default_rng(11)
+    for t in np.concatenate([-np.logspace(-12, 2.8, 400), [0.0, -1e-300]]):
+        assert abs(oracle.exp_nonpos(t) - math.exp(t)) <= 4e-16 * math.exp(t)
+    assert oracle.exp_nonpos(-800.0) == 0.0 and oracle.exp_nonpos(-np.inf) == 0.0 and math.isnan(oracle.exp_nonpos(float("nan")))
+    N, B = 100_000, 10
+    lw = -0.5 * rng.chisquare(32, N) - 40.0
+    a_log = oracle.metropolis_log(lw, B, 7, step=3)
+    a_den = oracle.metropolis(np.exp(lw), B, 7, step=3)
+    assert np.mean(a_log != a_den) < 1e-4
+    deep = lw - 2000.0                      # exp() of these is 0: the density chain would see 0/0 everywhere
+    assert np.array_equal(oracle.metropolis_log(deep, B, 7, step=3), a_log)   # only differences matter
+    assert np.array_equal(oracle.metropolis(np.exp(deep), B, 7, step=3), np.arange(N))  # NaN ratios never accept
+    lw2 = lw.copy(); lw2[::5] = -np.inf    # zero weights: never entered
+    a2 = oracle.metropolis_log(lw2, B, 7, step=3)
+    moved = a2 != np.arange(N)
+    assert not np.isinf(lw2[a2[moved]]).any()
