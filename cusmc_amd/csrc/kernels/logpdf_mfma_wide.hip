@@ -318,6 +318,10 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
       }
       return odd;
     };
+    // (Tried: in the single-member phase the 16 fragment registers can hold a ring of four k-blocks,
+    // i.e. fragments requested three k-blocks ahead at no register cost.  No gain -- 661..670 us
+    // against 654..660 in the calibration run -- so the fragment latency is not what the two streams
+    // cost each other.)
     if constexpr (TRI) {
       const bool odd = run_phase(std::integral_constant<int, 2>{}, 0, lo + 1, false);
       run_phase(std::integral_constant<int, 1>{}, lo + 1, hi + 1, odd);
