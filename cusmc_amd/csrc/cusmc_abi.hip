@@ -118,6 +118,8 @@ struct cusmc_ctx {
   DevBuf scratch[6];  // host-pointer entry points: X, out, w, a, small matrices
   StagingRing ring;  // pinned staging for small parameter uploads
   DevBuf whi;        // high words of the weight vector (resampler, large N)
+  DevBuf step_mats;  // [Q | G] of the fused filter step, re-uploaded only when they change
+  std::vector<double> step_mats_host;
 };
 
 struct cusmc_dist {
@@ -357,6 +359,7 @@ CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &b : ctx->scratch) b.release();
   ctx->whi.release();
+  ctx->step_mats.release();
   ctx->ring.release();
   delete ctx;
   return CUSMC_OK;
@@ -748,11 +751,19 @@ CUSMC_EXPORT int cusmc_pf_step_dev(cusmc_dist *obs, int kind, float nu, const do
   if (int rc = plan_affine(obs, y, F)) return rc;
   if (int rc = ensure_M(obs)) return rc;
   const size_t dd = (size_t)d * d;
-  // device image [Q | G]: the small matrices are read through wave-uniform (scalar) loads
-  if (int rc = ctx->scratch[4].reserve(2 * dd * 8)) return rc;
-  if (int rc = upload_small(ctx, ctx->scratch[4], 0, Q, dd)) return rc;
-  if (int rc = upload_small(ctx, ctx->scratch[4], dd, G, dd)) return rc;
-  const double *base = (const double *)ctx->scratch[4].p;
+  // device image [Q | G]: the small matrices are read through wave-uniform (scalar) loads.  A filter
+  // calls this once per time step with the same matrices: upload only what changed.
+  {
+    std::vector<double> img(2 * dd);
+    std::copy(Q, Q + dd, img.begin());
+    std::copy(G, G + dd, img.begin() + dd);
+    if (img != ctx->step_mats_host || !ctx->step_mats.p) {
+      if (int rc = ctx->step_mats.reserve(2 * dd * 8)) return rc;
+      if (int rc = ctx->ring.upload(ctx->step_mats.p, img.data(), 2 * dd * 8, ctx->stream)) return rc;
+      ctx->step_mats_host.swap(img);
+    }
+  }
+  const double *base = (const double *)ctx->step_mats.p;
   const uint32_t *whi = nullptr;
   if (cusmc::metropolis_wants_hiwords(N) && B > 1) {
     if (int rc = ctx->whi.reserve((size_t)N * 4)) return rc;

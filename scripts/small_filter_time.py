@@ -10,7 +10,8 @@ for (N, d, T) in [(1000, 2, 100), (10_000, 2, 100), (100_000, 2, 100), (1000, 8,
     ts = []
     for _ in range(5):
         t0 = time.perf_counter()
-        cusmc_amd.run(N, d, T, Y, np.zeros(d), I, I, I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn", seed=3)
-        ts.append(time.perf_counter() - t0)
+        res = cusmc_amd.run(N, d, T, Y, np.zeros(d), I, I, I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn", seed=3)
+        ts.append(time.perf_counter() - t0)  # (result kept alive: freeing it is not part of run())
+        del res
     t = min(ts)
     print("run N=%d d=%d T=%d: %.2f ms total, %.1f us per time step" % (N, d, T, t * 1e3, t / (T - 1) * 1e6))
