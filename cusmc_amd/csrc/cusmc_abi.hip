@@ -135,6 +135,7 @@ struct cusmc_dist {
   int plan = 0;  // 0 none, 1 centred, 2 affine
   bool plan_tri = true;
   std::vector<double> plan_F, plan_shift, plan_bias;
+  std::vector<double> plan_Qt;  // affine plan, d >= 16: Q^T of -W F = Q L (hostM holds L)
   bool frags_valid = false, M_valid = false;
   int frags_kind = 0;  // which kernel family the device fragments are packed for (1 tile, 2 wide)
   std::vector<double> hostM;
@@ -209,8 +210,10 @@ int ensure_frags(cusmc_dist *dist, int kind)
 {
   if (dist->frags_valid && dist->frags_kind == kind) return CUSMC_OK;
   const int d = dist->d, nb = kind == 2 ? cusmc::mfma_wide_nb(d) : (d + 15) / 16, dp = 16 * nb;
-  const size_t n = kind == 2 ? cusmc::mfma_wide_frag_doubles(nb, dist->plan_tri)
-                             : (size_t)cusmc::mfma_num_frags(nb, dist->plan_tri) * 64;
+  // (the matrix-core kernels take lower triangular factors only: plan_affine() rotates)
+  if (!dist->plan_tri) return fail(CUSMC_EINVAL, "internal: dense factor on the matrix-core path");
+  const size_t n = kind == 2 ? cusmc::mfma_wide_frag_doubles(nb)
+                             : (size_t)cusmc::mfma_num_frags(nb, true) * 64;
   std::vector<double> frags(n, 0.0);
   // zero-pad M to 16*nb when d is not that already: the extra output rows give z = 0, the extra
   // columns only ever meet zeros (the kernels mask what they load there)
@@ -222,9 +225,9 @@ int ensure_frags(cusmc_dist *dist, int kind)
     M = Mp.data();
   }
   if (kind == 2)
-    cusmc::mfma_wide_pack_frags(M, dp, dist->plan_tri, frags.data());
+    cusmc::mfma_wide_pack_frags(M, dp, frags.data());
   else
-    cusmc::mfma_pack_frags(M, dp, dist->plan_tri, frags.data());
+    cusmc::mfma_pack_frags(M, dp, true, frags.data());
   if (int rc = dist->frags.reserve(n * 8)) return rc;
   if (int rc = dist->ctx->ring.upload(dist->frags.p, frags.data(), n * 8, dist->ctx->stream)) return rc;
   dist->frags_valid = true;
@@ -252,14 +255,14 @@ int run_logpdf(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx, in
   for (double v : dist->plan_shift) has_shift |= (v != 0.0);
   if (cusmc::mfma_wide_supported(d, X_dev, ldx)) {
     if (int rc = ensure_frags(dist, 2)) return rc;
-    HIP_TRY(cusmc::launch_logpdf_mfma_wide(X_dev, N, ldx, d, dist->plan_tri, has_shift,
+    HIP_TRY(cusmc::launch_logpdf_mfma_wide(X_dev, N, ldx, d, dist->plan == 1, has_shift,
                                            (const double *)dist->frags.p, (const double *)dist->shift.p,
                                            (const double *)dist->bias.p, ep, out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
   if (cusmc::mfma_supported(d, X_dev, ldx)) {
     if (int rc = ensure_frags(dist, 1)) return rc;
-    HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan_tri, has_shift, (const double *)dist->frags.p,
+    HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan == 1, has_shift, (const double *)dist->frags.p,
                                       (const double *)dist->shift.p, (const double *)dist->bias.p,
                                       ep, out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
@@ -306,13 +309,29 @@ int plan_affine(cusmc_dist *dist, const double *y, const double *F)
   std::vector<double> M, bias;
   const bool cached = dist->plan == 2 && dist->plan_F.size() == (size_t)d * d &&
                       !memcmp(dist->plan_F.data(), F, (size_t)d * d * 8);
+  // d >= 16 (matrix-core kernels): only |z|^2 is wanted, so rotate z by the Q^T of -W F = Q L.  The
+  // kernels then multiply by a lower triangular L -- d(d+1)/2 products per particle instead of
+  // d^2 -- and the bias Q^T W y enters as the accumulators' initial value.
+  const bool rotate = d >= 16;
   if (!cached) {
     cusmc::la::matmul(dist->W.data(), F, d, M);
     for (double &v : M) v = -v;
+    if (rotate && !cusmc::la::is_lower_triangular(M.data(), d)) {
+      std::vector<double> L;
+      cusmc::la::ql_factor(M.data(), d, L, dist->plan_Qt);
+      M.swap(L);
+    } else {
+      dist->plan_Qt.clear();
+    }
   }
   cusmc::la::matvec(dist->W.data(), y, d, bias);
+  if (!dist->plan_Qt.empty()) {
+    std::vector<double> rb;
+    cusmc::la::matvec(dist->plan_Qt.data(), bias.data(), d, rb);
+    bias.swap(rb);
+  }
   const std::vector<double> shift(d, 0.0);
-  return install_plan(dist, 2, false, cached ? dist->hostM : M, F, shift, bias);
+  return install_plan(dist, 2, rotate, cached ? dist->hostM : M, F, shift, bias);
 }
 
 }  // namespace

@@ -87,6 +87,59 @@ inline bool is_diagonal(const double *A, int n)
   return true;
 }
 
+inline bool is_lower_triangular(const double *A, int n)
+{
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+      if (A[(size_t)i * n + j] != 0.0) return false;
+  return true;
+}
+
+// QL factorisation by Householder reflections: M = Q L with Q orthogonal and L lower triangular
+// (both n x n, row-major).  Returns L and Qt = Q^T, so that for any b
+//     |b + M x|^2 = |Qt b + L x|^2.
+// Used to give reweight_G's dense matrix -W F (src/mcmc.cpp:208 via statistics.cc.cpp:171-180) the
+// triangular shape the matrix-core kernels run; works for singular M as well.
+inline void ql_factor(const double *M, int n, std::vector<double> &L, std::vector<double> &Qt)
+{
+  L.assign(M, M + (size_t)n * n);
+  Qt.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) Qt[(size_t)i * n + i] = 1.0;
+  std::vector<double> v(n);
+  for (int k = n - 1; k >= 1; --k) {
+    // reflect rows 0..k so that column k becomes (0, ..., 0, alpha)
+    double scale = 0.0;
+    for (int i = 0; i <= k; ++i) scale = std::fmax(scale, std::fabs(L[(size_t)i * n + k]));
+    if (scale == 0.0) continue;
+    double norm2 = 0.0;
+    for (int i = 0; i <= k; ++i) {
+      v[i] = L[(size_t)i * n + k] / scale;
+      norm2 += v[i] * v[i];
+    }
+    const double norm = std::sqrt(norm2);
+    const double alpha = v[k] > 0.0 ? -norm : norm;  // (no cancellation in v[k] - alpha)
+    const double vk = v[k] - alpha;
+    const double vnorm2 = norm2 - v[k] * v[k] + vk * vk;
+    v[k] = vk;
+    if (vnorm2 == 0.0) continue;
+    const double beta = 2.0 / vnorm2;
+    for (int c = 0; c < k; ++c) {  // H = I - beta v v^T on the columns still to do
+      double s = 0.0;
+      for (int i = 0; i <= k; ++i) s += v[i] * L[(size_t)i * n + c];
+      s *= beta;
+      for (int i = 0; i <= k; ++i) L[(size_t)i * n + c] -= s * v[i];
+    }
+    for (int i = 0; i < k; ++i) L[(size_t)i * n + k] = 0.0;
+    L[(size_t)k * n + k] = alpha * scale;
+    for (int c = 0; c < n; ++c) {
+      double s = 0.0;
+      for (int i = 0; i <= k; ++i) s += v[i] * Qt[(size_t)i * n + c];
+      s *= beta;
+      for (int i = 0; i <= k; ++i) Qt[(size_t)i * n + c] -= s * v[i];
+    }
+  }
+}
+
 // Q = V sqrt(Lambda) from the symmetric eigen-decomposition S = V Lambda V^T, the matrix
 // eigenSolver() builds (src/linear_algebra.cpp:13-22 through Eigen's SelfAdjointEigenSolver).
 // Same route as Eigen's: Householder reduction to tridiagonal form, then implicit QL sweeps (the

@@ -34,17 +34,17 @@ void mfma_pack_frags(const double *M, int d, bool tri, double *frags)
         }
 }
 
-template <int NB, bool TRI, bool SHIFT, int EPI, bool PAD>
+template <int NB, bool CENTRED, bool SHIFT, int EPI, bool PAD>
 static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, int d, const double *frags,
                             const double *shift, const double *bias, const Epilogue &ep,
                             double *out, int num_cus, hipStream_t stream)
 {
-  constexpr int NFRAG = TRI ? 4 * NB * (NB + 1) / 2 : 4 * NB * NB;
-  constexpr bool WREG = mfma_factor_in_regs<NB, TRI>();
+  constexpr int NFRAG = 4 * NB * (NB + 1) / 2;  // lower triangular in both forms
+  constexpr bool WREG = mfma_factor_in_regs<NB>();
   constexpr int THREADS = mfma_threads<NB>();
   const size_t lds_bytes = (size_t)(32 * NB + 4 + (WREG ? 0 : NFRAG * 64)) * sizeof(double);
   const long num_tiles = (N + 15) / 16;
-  auto kern = logpdf_mfma_kernel<NB, TRI, SHIFT, 0, EPI, PAD>;
+  auto kern = logpdf_mfma_kernel<NB, CENTRED, SHIFT, 0, EPI, PAD>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -59,7 +59,9 @@ static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, int d, cons
   return hipGetLastError();
 }
 
-hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+// frags: mfma_pack_frags(., ., tri = true, .) of the lower triangular factor.  centred: z = L (x -
+// shift); otherwise z = bias + L x (the QL-rotated affine form, cusmc_abi.hip plan_affine()).
+hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool centred,
                               bool has_shift, const double *frags, const double *shift,
                               const double *bias, const Epilogue &ep, double *out, int num_cus,
                               hipStream_t stream)
@@ -73,7 +75,7 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
 #define CUSMC_EPI(nb, t, s) (epi == 1 ? CUSMC_PADV(nb, t, s, 1) : epi == 2 ? CUSMC_PADV(nb, t, s, 2) : CUSMC_PADV(nb, t, s, 0))
 #define CUSMC_CASE(nb)                                                                            \
   case nb:                                                                                        \
-    if (!tri) return CUSMC_EPI(nb, false, false);                                                 \
+    if (!centred) return CUSMC_EPI(nb, false, false);                                               \
     return has_shift ? CUSMC_EPI(nb, true, true) : CUSMC_EPI(nb, true, false);
   switch ((d + 15) / 16) {
     CUSMC_CASE(1)

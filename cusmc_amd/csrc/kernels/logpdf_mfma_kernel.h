@@ -68,8 +68,14 @@ __device__ __forceinline__ double finish_epi(double q, const Epilogue &ep)
   return finish(q, ep);
 }
 
-// TRI  = centred form:  z = W (x - shift), W lower triangular, no bias      (pdf(y, F))
-// !TRI = affine form:   z = bias + M x,    M dense, no shift                (reweight_G)
+// CENTRED  = centred form:  z = W (x - shift), no bias                       (pdf(y, F))
+// !CENTRED = affine form:   z = bias + L x,    no shift                      (reweight_G)
+// The factor is lower triangular in BOTH forms.  reweight_G's z = W y - (W F) x has a dense matrix
+// M = -W F, but only |z|^2 is wanted and that is invariant under rotations of z: the host factors
+// M = Q L (Householder QL, hostla.h) and hands the kernel L and the rotated bias Q^T W y, so a
+// general observation matrix F costs the same 40 block-products per tile at d = 64 as F = I does,
+// not the 64 of the dense product (133 -> 9x us for 1e6 particles).  The bias is
+// the initial accumulator of each output block's first MFMA: it costs no instruction at all.
 // SHIFT = false drops the subtraction when the shift vector is all zeros.
 // EPI fixes the epilogue at compile time: 1 = MVN log-density (lognorm - q/2), 2 = Student-t
 // log-density (lognorm - (nu+d)/2 log1p(q/nu), log1p through the library's own ln: smallops.h),
@@ -147,13 +153,13 @@ __host__ __device__ constexpr int mfma_threads()
   // better at d = 80, worse at d = 112 and for the Student-t epilogue: not worth the spills)
   return NB == 1 ? 1024 : NB == 2 ? 768 : NB <= 4 ? 512 : 256;
 }
-template <int NB, bool TRI>
+template <int NB>
 __host__ __device__ constexpr bool mfma_factor_in_regs()
 {
 #ifdef EXP_LDSW
   return false;
 #else
-  return TRI && NB <= 4;
+  return NB <= 4;
 #endif
 }
 template <int NB, bool SHIFT, int EPI>
@@ -175,7 +181,7 @@ __host__ __device__ constexpr int mfma_sets()  // operand register sets in rotat
 #endif
 }
 
-template <int NB, bool TRI, bool SHIFT, int ABL = 0, int EPI = 0, bool PAD = false>
+template <int NB, bool CENTRED, bool SHIFT, int ABL = 0, int EPI = 0, bool PAD = false>
 __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     const double *__restrict__ X, long N, long ldx, const double *__restrict__ frags,
     const double *__restrict__ shift, const double *__restrict__ bias, Epilogue ep,
@@ -186,8 +192,8 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   constexpr bool NOLOAD = ABL == 1 || ABL == 5;
   unsigned long long stamp_entry = 0;
   if (STAMP) stamp_entry = __builtin_amdgcn_s_memrealtime();
-  constexpr int NFRAG = TRI ? 4 * NB * (NB + 1) / 2 : 4 * NB * NB;
-  constexpr bool WREG = mfma_factor_in_regs<NB, TRI>();
+  constexpr int NFRAG = 4 * NB * (NB + 1) / 2;
+  constexpr bool WREG = mfma_factor_in_regs<NB>();
   extern __shared__ double lds[];
   double *sShift = lds;              // 16*NB
   double *sBias = sShift + 16 * NB;  // 16*NB
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
       }
     }
   }
-  if ((SHIFT || !TRI) && threadIdx.x < 16 * NB) {  // (a cold miss in front of the barrier otherwise)
+  if ((SHIFT || !CENTRED) && threadIdx.x < 16 * NB) {  // (a cold miss in front of the barrier otherwise)
     sShift[threadIdx.x] = shift[threadIdx.x];
     sBias[threadIdx.x] = bias[threadIdx.x];
   }
@@ -292,12 +298,21 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   __syncthreads();
   // the shift values a lane subtracts are the same for every tile: 4*NB registers instead of
   // 4*NB LDS reads per tile (d <= 64; above that the registers are spoken for)
-  double shreg[(SHIFT && WREG) ? NB : 1][4];
-  if constexpr (SHIFT && WREG) {
+  double shreg[(CENTRED && SHIFT && WREG) ? NB : 1][4];
+  if constexpr (CENTRED && SHIFT && WREG) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) shreg[kb][s4] = sShift[16 * kb + pi_k(s4, h)];
+  }
+  // likewise the affine form's bias: C rows of block cb are output dims 16 cb + h + 4r
+  v4d breg[(!CENTRED && WREG) ? NB : 1];
+  if constexpr (!CENTRED && WREG) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const double *b = sBias + 16 * cb + h;
+      breg[cb] = v4d{b[0], b[4], b[8], b[12]};
+    }
   }
   // (!WREG) the factor fragments are loop-invariant LDS reads; left alone, hipcc hoists all of
   // them out of the tile loop into spilled registers.  An opaque per-tile lane offset keeps them
@@ -309,8 +324,10 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     v4d acc[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
-      if (TRI) {
+      if (CENTRED) {
         acc[cb] = v4d{0.0, 0.0, 0.0, 0.0};
+      } else if (WREG) {
+        acc[cb] = breg[cb];
       } else {  // C rows are output dims h + 4r of block cb
         const double *b = sBias + 16 * cb + h;
         acc[cb] = v4d{b[0], b[4], b[8], b[12]};
@@ -323,7 +340,7 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           double a = a_in[kb][s >> 1][s & 1];
-          if (SHIFT) a -= shreg[kb][s];
+          if (CENTRED && SHIFT) a -= shreg[kb][s];
 #pragma unroll
           for (int cb = kb; cb < NB; ++cb, ++f) {
             if (ABL == 2)
@@ -343,16 +360,16 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
       for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int lo = TRI ? kb : 0;
+          const int lo = kb;
           const int cnt = NB - lo;
           const int kbn = s == 3 ? kb + 1 : kb;  // the next step's k-block
-          const int lon = TRI ? kbn : 0;
+          const int lon = kbn;
           if (kbn < NB) {
 #pragma unroll
             for (int cb = lon; cb < NB; ++cb) w_nxt[cb] = sF[(f + cnt + cb - lon) * 64 + lds_lane];
           }
           double a = a_in[kb][s >> 1][s & 1];
-          if (TRI && SHIFT) a -= sShift[16 * kb + pi_k(s, h)];
+          if (CENTRED && SHIFT) a -= sShift[16 * kb + pi_k(s, h)];
 #pragma unroll
           for (int cb = lo; cb < NB; ++cb) {
             if (ABL == 2)

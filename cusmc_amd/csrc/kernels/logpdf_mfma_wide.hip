@@ -2,7 +2,7 @@
 // the regime where (X - mu) L^-T is a genuine dense GEMM and the kernel is bound by the f64 matrix
 // cores, not by HBM (d = 256: 2056 B and ~70 kflop per particle = 34 flop/B against a machine
 // balance of 9.8).  Same contract and same reference functions as kernels/logpdf_mfma_kernel.h:
-//     z = bias + M (x - shift),  q = z.z,  out = epilogue(q)
+//     z = L (x - shift)  or  z = bias + L x,  L lower triangular,  q = z.z,  out = epilogue(q)
 //
 // Why a second kernel.  At d = 256 the block-triangular factor is 278 KB: it fits neither the
 // register file nor LDS, and one wave cannot hold 16 output blocks of accumulators for several
@@ -71,9 +71,8 @@ static bool wide_needs_pad(int d, const void *X, int64_t ldx)
 }
 
 // fragments in the stream of pair q (kernel loop order: kb, s, live members)
-static long wide_stream_frags(int nb, bool tri, int q)
+static long wide_stream_frags(int nb, int q)
 {
-  if (!tri) return 8L * nb;                      // both blocks at every k-block
   return 4L * (2 * (q + 1) + (nb - 1 - 2 * q));  // both up to kb = q, then the high block alone
 }
 
@@ -83,18 +82,18 @@ static size_t wide_lds_bytes(int nb)
   return (size_t)(2 * nb * 4 * tiles * 64 + 2 * wide_waves(nb) * 32 + 32 * nb) * sizeof(double);
 }
 
-size_t mfma_wide_frag_doubles(int nb, bool tri)
+size_t mfma_wide_frag_doubles(int nb)
 {
   size_t n = 0;
-  for (int q = 0; q < wide_pairs(nb); ++q) n += (size_t)wide_stream_frags(nb, tri, q) * 64;
+  for (int q = 0; q < wide_pairs(nb); ++q) n += (size_t)wide_stream_frags(nb, q) * 64;
   return n + 9 * 64;  // zero tail: the kernel prefetches one k-block past a stream's end
 }
 
 // streams back to back; a fragment holds, for lane l = (j, h), M[16*cb + j][16*kb + pi(s,h)]
-void mfma_wide_pack_frags(const double *M, int d, bool tri, double *frags)
+void mfma_wide_pack_frags(const double *M, int d, double *frags)
 {
   const int nb = d / 16;
-  const size_t total = mfma_wide_frag_doubles(nb, tri);
+  const size_t total = mfma_wide_frag_doubles(nb);
   for (size_t i = total - 9 * 64; i < total; ++i) frags[i] = 0.0;
   size_t f = 0;
   for (int q = 0; q < wide_pairs(nb); ++q) {
@@ -103,7 +102,7 @@ void mfma_wide_pack_frags(const double *M, int d, bool tri, double *frags)
       for (int s = 0; s < 4; ++s)
         for (int m = 0; m < 2; ++m) {
           const int cb = m ? hi : lo;
-          if (tri && cb < kb) continue;
+          if (cb < kb) continue;  // (lower triangular)
           for (int l = 0; l < 64; ++l) {
             const int j = l & 15, h = l >> 4;
             frags[f * 64 + l] = M[(size_t)(16 * cb + j) * d + 16 * kb + wide_pi(s, h)];
@@ -124,7 +123,7 @@ struct WideStreams { int byte_off[8]; };  // start of each pair's fragment strea
 
 // ABL (scripts/calib only; 0 in the library): 1 = fragments not re-fetched, 2 = next group's rows
 // not fetched, 3 = neither.  Attribution of stall time; results are wrong by construction.
-template <int NB, bool TRI, bool SHIFT, int ABL = 0, bool PAD = false>
+template <int NB, bool CENTRED, bool SHIFT, int ABL = 0, bool PAD = false>
 __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_kernel(
     const double *__restrict__ X, long N, long ldx, const double *__restrict__ frags,
     WideStreams streams, long frag_bytes, const double *__restrict__ shift,
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       v4d init = v4d{0.0, 0.0, 0.0, 0.0};
-      if (!TRI) {  // C rows are output dims h + 4r of block cb
+      if (!CENTRED) {  // C rows are output dims h + 4r of block cb
         const double *b = sBias + 16 * (m ? hi : lo) + h;
         init = v4d{b[0], b[4], b[8], b[12]};
       }
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
             r1 = keepc ? r1 : 0.0;
           }
         }
-        if (TRI && SHIFT) {
+        if (CENTRED && SHIFT) {
           const double sh = sShift[16 * kb + wide_pi(s, h)];
           r0 -= sh;
           r1 -= sh;
@@ -322,11 +321,9 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
     // i.e. fragments requested three k-blocks ahead at no register cost.  No gain -- 661..670 us
     // against 654..660 in the calibration run -- so the fragment latency is not what the two streams
     // cost each other.)
-    if constexpr (TRI) {
+    {
       const bool odd = run_phase(std::integral_constant<int, 2>{}, 0, lo + 1, false);
       run_phase(std::integral_constant<int, 1>{}, lo + 1, hi + 1, odd);
-    } else {
-      run_phase(std::integral_constant<int, 2>{}, 0, NB, false);
     }
 
     // partial sums of squares over this wave's two output blocks, per particle
@@ -353,24 +350,24 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
   }
 }
 
-template <int NB, bool TRI>
+template <int NB>
 static WideStreams wide_streams()
 {
   WideStreams st{};
   long off = 0;
   for (int q = 0; q < wide_pairs(NB); ++q) {
     st.byte_off[q] = (int)(off * 8);
-    off += wide_stream_frags(NB, TRI, q) * 64;
+    off += wide_stream_frags(NB, q) * 64;
   }
   return st;
 }
 
-template <int NB, bool TRI, bool SHIFT, bool PAD>
+template <int NB, bool CENTRED, bool SHIFT, bool PAD>
 static hipError_t launch_wide(const double *X, int64_t N, int64_t ldx, int d, const double *frags,
                               const double *shift, const double *bias, const Epilogue &ep,
                               double *out, int num_cus, hipStream_t stream)
 {
-  auto kern = logpdf_mfma_wide_kernel<NB, TRI, SHIFT, 0, PAD>;
+  auto kern = logpdf_mfma_wide_kernel<NB, CENTRED, SHIFT, 0, PAD>;
   const size_t lds_bytes = wide_lds_bytes(NB);
   static bool configured = false;
   if (!configured) {
@@ -383,9 +380,9 @@ static hipError_t launch_wide(const double *X, int64_t N, int64_t ldx, int d, co
   const long num_groups = (N + GP - 1) / GP;
   long blocks = num_cus;  // one workgroup per CU (two staging buffers fill the LDS)
   if (blocks > num_groups) blocks = num_groups;
-  const long frag_bytes = (long)mfma_wide_frag_doubles(NB, TRI) * 8;
+  const long frag_bytes = (long)mfma_wide_frag_doubles(NB) * 8;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * (wide_waves(NB) + 1)), lds_bytes, stream, X, (long)N,
-                     (long)ldx, frags, wide_streams<NB, TRI>(), frag_bytes, shift, bias, ep, out, num_groups, d);
+                     (long)ldx, frags, wide_streams<NB>(), frag_bytes, shift, bias, ep, out, num_groups, d);
   return hipGetLastError();
 }
 
@@ -395,14 +392,14 @@ hipError_t launch_wide_ablate(int abl, const double *X, int64_t N, const double 
 {
   Epilogue ep{-10.0, 0, 0, 0, 0};
   const long num_groups = (N + 31) / 32;
-  const long fb = (long)mfma_wide_frag_doubles(16, true) * 8;
+  const long fb = (long)mfma_wide_frag_doubles(16) * 8;
   const size_t lds = wide_lds_bytes(16);
 #define CUSMC_ABL(a)                                                                                           \
   case a:                                                                                                      \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(logpdf_mfma_wide_kernel<16, true, false, a>),     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
     hipLaunchKernelGGL((logpdf_mfma_wide_kernel<16, true, false, a>), dim3(blocks), dim3(576), lds, stream, X, \
-                       (long)N, 256L, frags, wide_streams<16, true>(), fb, zeros, zeros, ep, out, num_groups);  \
+                       (long)N, 256L, frags, wide_streams<16>(), fb, zeros, zeros, ep, out, num_groups);  \
     break;
   switch (abl) { CUSMC_ABL(0) CUSMC_ABL(1) CUSMC_ABL(2) CUSMC_ABL(3) }
 #undef CUSMC_ABL
@@ -419,7 +416,7 @@ int wide_occupancy_probe()
   return n;
 }
 
-hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int d, bool centred,
                                    bool has_shift, const double *frags, const double *shift,
                                    const double *bias, const Epilogue &ep, double *out,
                                    int num_cus, hipStream_t stream)
@@ -431,7 +428,7 @@ hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int 
        : launch_wide<nb, t, s, false>(X, N, ldx, d, frags, shift, bias, ep, out, num_cus, stream))
 #define CUSMC_WIDE(nb)                                                                             \
   case nb:                                                                                         \
-    if (!tri) return CUSMC_WPAD(nb, false, false);                                                 \
+    if (!centred) return CUSMC_WPAD(nb, false, false);                                              \
     return has_shift ? CUSMC_WPAD(nb, true, true) : CUSMC_WPAD(nb, true, false);
   switch (mfma_wide_nb(d)) {
     CUSMC_WIDE(12)

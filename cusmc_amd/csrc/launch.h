@@ -21,6 +21,8 @@ struct Epilogue {
 //     z = bias + M (x - shift),   q = z.z,   out = epilogue(q)
 // centred form  (pdf(y,F)):   M = W = L^-1 (lower triangular), shift = F mu, bias = 0
 // affine form   (reweight_G): M = -W F (dense),                shift = 0,    bias = W y
+//   -- for d >= 16 rotated on the host to M = L (lower triangular), bias = Q^T W y with -W F = Q L:
+//   |z|^2 does not change and the matrix-core kernels only ever see triangular factors
 
 // --- kernels/logpdf_mfma.hip : d = 16*NB, v_mfma_f64_16x16x4_f64 -------------------------------
 // Number of 512-byte B fragments the kernel expects in `frags` (LDS image, kernel loop order).
@@ -29,9 +31,9 @@ int mfma_num_frags(int nb, bool tri);
 bool mfma_supported(int d, const void *X, int64_t ldx);
 // Host-side packing of M (d x d row-major) into the fragment order.
 void mfma_pack_frags(const double *M, int d, bool tri, double *frags);
-// tri: centred form (shift, no bias); !tri: affine form (bias, no shift).  has_shift = false
-// promises the shift vector is all zeros.
-hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+// frags: the LOWER TRIANGULAR factor packed with tri = true.  centred: shift, no bias; !centred:
+// bias, no shift.  has_shift = false promises the shift vector is all zeros.
+hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool centred,
                               bool has_shift, const double *frags, const double *shift,
                               const double *bias, const Epilogue &ep, double *out, int num_cus,
                               hipStream_t stream);
@@ -39,9 +41,9 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
 // --- kernels/logpdf_mfma_wide.hip : 128 < d <= 256, output blocks split over the waves -----------
 bool mfma_wide_supported(int d, const void *X, int64_t ldx);
 int mfma_wide_nb(int d);  // 16-column blocks the wide kernel runs d with (8, 12 or 16)
-size_t mfma_wide_frag_doubles(int nb, bool tri);
-void mfma_wide_pack_frags(const double *M, int d, bool tri, double *frags);
-hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int d, bool tri,
+size_t mfma_wide_frag_doubles(int nb);
+void mfma_wide_pack_frags(const double *M, int d, double *frags);
+hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int d, bool centred,
                                    bool has_shift, const double *frags, const double *shift,
                                    const double *bias, const Epilogue &ep, double *out,
                                    int num_cus, hipStream_t stream);

@@ -3,8 +3,8 @@
 #include <cstdio>
 #include <vector>
 namespace cusmc {
-size_t mfma_wide_frag_doubles(int nb, bool tri);
-void mfma_wide_pack_frags(const double *M, int d, bool tri, double *frags);
+size_t mfma_wide_frag_doubles(int nb);
+void mfma_wide_pack_frags(const double *M, int d, double *frags);
 int wide_occupancy_probe();
 hipError_t launch_wide_ablate(int abl, const double *X, int64_t N, const double *frags, const double *zeros, double *out, int blocks, hipStream_t stream);
 }
@@ -13,7 +13,7 @@ int main() {
   std::vector<double> M((size_t)d * d, 0.0), hX((size_t)N * d);
   unsigned s = 1; for (auto &v : hX) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) - (1 << 23)) * (1.0 / (1 << 22)); }
   for (int i = 0; i < d; ++i) for (int j = 0; j <= i; ++j) { s = s * 1664525u + 1013904223u; M[i * d + j] = (i == j) + 0.05 * ((int)(s >> 8) - (1 << 23)) * (1.0 / (1 << 23)); }
-  std::vector<double> fr(cusmc::mfma_wide_frag_doubles(16, true)); cusmc::mfma_wide_pack_frags(M.data(), d, true, fr.data());
+  std::vector<double> fr(cusmc::mfma_wide_frag_doubles(16)); cusmc::mfma_wide_pack_frags(M.data(), d, fr.data());
   double *X, *F, *Z, *out; hipMalloc(&X, hX.size() * 8); hipMalloc(&F, fr.size() * 8); hipMalloc(&Z, 4096); hipMalloc(&out, N * 8);
   hipMemcpy(X, hX.data(), hX.size() * 8, hipMemcpyHostToDevice); hipMemcpy(F, fr.data(), fr.size() * 8, hipMemcpyHostToDevice); hipMemset(Z, 0, 4096);
   printf("occupancy API: %d workgroups/CU\n", cusmc::wide_occupancy_probe());
