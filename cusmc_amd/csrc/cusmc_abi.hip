@@ -737,6 +737,63 @@ CUSMC_EXPORT int cusmc_eigen_sqrt(const double *sigma, int d, double *Q)
 
 // ---- one filter time step -------------------------------------------------------------------
 
+// ---- fused filter step (d <= 8): host-side pieces --------------------------------------------------
+namespace {
+
+bool pf_step_is_fused(int d, uint32_t count)
+{
+  // One launch instead of three pays where launches are what a step costs (small shards) or where the
+  // state is a register pair (d <= 2); a big shard at d = 8 is quicker through the three specialised
+  // kernels (105 vs 120 us for 1e6 particles): the fused kernel's register footprint halves occupancy.
+  return cusmc::pf_step_supported(d) && (d <= 2 || count <= 200000u);
+}
+
+// observation plan for y, and the device image [Q | G]: the small matrices are read through
+// wave-uniform (scalar) loads.  A filter calls this with the same matrices at every time step:
+// only what changed is uploaded.
+int pf_step_prepare(cusmc_dist *obs, const double *G, const double *Q, const double *y, const double *F)
+{
+  cusmc_ctx *ctx = obs->ctx;
+  const int d = obs->d;
+  if (int rc = plan_affine(obs, y, F)) return rc;
+  if (int rc = ensure_M(obs)) return rc;
+  const size_t dd = (size_t)d * d;
+  std::vector<double> img(2 * dd);
+  std::copy(Q, Q + dd, img.begin());
+  std::copy(G, G + dd, img.begin() + dd);
+  if (img != ctx->step_mats_host || !ctx->step_mats.p) {
+    if (int rc = ctx->step_mats.reserve(2 * dd * 8)) return rc;
+    if (int rc = ctx->ring.upload(ctx->step_mats.p, img.data(), 2 * dd * 8, ctx->stream)) return rc;
+    ctx->step_mats_host.swap(img);
+  }
+  return CUSMC_OK;
+}
+
+// the launch(es) of one fused step; shift_dev / bias_dev: the observation plan's vectors for this
+// step's y (obs->shift / obs->bias, or rows of a table uploaded ahead of a whole time loop)
+int pf_step_launch(cusmc_dist *obs, int kind, float nu, const double *w_prev_dev, const double *X_prev_dev,
+                   uint32_t N, uint32_t B, double scale, uint64_t seed, uint32_t step, uint32_t first,
+                   uint32_t count, uint32_t *a_out_dev, double *X_out_dev, double *w_out_dev, int flags,
+                   const double *shift_dev, const double *bias_dev)
+{
+  cusmc_ctx *ctx = obs->ctx;
+  const int d = obs->d;
+  const size_t dd = (size_t)d * d;
+  const double *base = (const double *)ctx->step_mats.p;
+  const uint32_t *whi = nullptr;
+  if (cusmc::metropolis_wants_hiwords(N) && B > 1) {
+    if (int rc = ctx->whi.reserve((size_t)N * 4)) return rc;
+    HIP_TRY(cusmc::launch_hiwords(w_prev_dev, N, (uint32_t *)ctx->whi.p, ctx->num_cus, ctx->stream));
+    whi = (const uint32_t *)ctx->whi.p;
+  }
+  HIP_TRY(cusmc::launch_pf_step(kind, nu, w_prev_dev, whi, X_prev_dev, N, d, B, base + dd, base, scale, obs->plan_tri,
+                                (const double *)obs->Mdev.p, shift_dev, bias_dev, make_epilogue(obs, flags), seed,
+                                step, first, count, a_out_dev, X_out_dev, w_out_dev, ctx->num_cus, ctx->stream));
+  return CUSMC_OK;
+}
+
+}  // namespace
+
 CUSMC_EXPORT int cusmc_pf_step_dev(cusmc_dist *obs, int kind, float nu, const double *w_prev_dev,
                                    const double *X_prev_dev, uint32_t N, const double *G,
                                    const double *Q, const double *y, const double *F, uint32_t B,
@@ -756,44 +813,16 @@ CUSMC_EXPORT int cusmc_pf_step_dev(cusmc_dist *obs, int kind, float nu, const do
   if (!w_prev_dev || !X_prev_dev || !a_out_dev || !X_out_dev || !w_out_dev)
     return fail(CUSMC_EINVAL, "null device pointer");
   const int d = obs->d;
-  // One launch instead of three pays where launches are what a step costs (small shards) or where the
-  // state is a register pair (d <= 2); a big shard at d = 8 is quicker through the three specialised
-  // kernels (105 vs 120 us for 1e6 particles): the fused kernel's register footprint halves occupancy.
-  const bool fused = cusmc::pf_step_supported(d) && (d <= 2 || count <= 200000u);
-  if (!fused) {
+  if (!pf_step_is_fused(d, count)) {
     if (int rc = cusmc_metropolis_dev(ctx, w_prev_dev, N, B, seed, step, first, count, a_out_dev)) return rc;
     if (int rc = draws(ctx, kind, nu, X_prev_dev, a_out_dev, G, Q, nullptr, d, scale, seed, step, 2u, first, count,
                        X_out_dev))
       return rc;
     return cusmc_dist_reweight_dev(obs, X_out_dev, count, d, y, F, flags, w_out_dev);
   }
-  if (int rc = plan_affine(obs, y, F)) return rc;
-  if (int rc = ensure_M(obs)) return rc;
-  const size_t dd = (size_t)d * d;
-  // device image [Q | G]: the small matrices are read through wave-uniform (scalar) loads.  A filter
-  // calls this once per time step with the same matrices: upload only what changed.
-  {
-    std::vector<double> img(2 * dd);
-    std::copy(Q, Q + dd, img.begin());
-    std::copy(G, G + dd, img.begin() + dd);
-    if (img != ctx->step_mats_host || !ctx->step_mats.p) {
-      if (int rc = ctx->step_mats.reserve(2 * dd * 8)) return rc;
-      if (int rc = ctx->ring.upload(ctx->step_mats.p, img.data(), 2 * dd * 8, ctx->stream)) return rc;
-      ctx->step_mats_host.swap(img);
-    }
-  }
-  const double *base = (const double *)ctx->step_mats.p;
-  const uint32_t *whi = nullptr;
-  if (cusmc::metropolis_wants_hiwords(N) && B > 1) {
-    if (int rc = ctx->whi.reserve((size_t)N * 4)) return rc;
-    HIP_TRY(cusmc::launch_hiwords(w_prev_dev, N, (uint32_t *)ctx->whi.p, ctx->num_cus, ctx->stream));
-    whi = (const uint32_t *)ctx->whi.p;
-  }
-  HIP_TRY(cusmc::launch_pf_step(kind, nu, w_prev_dev, whi, X_prev_dev, N, d, B, base + dd, base, scale, obs->plan_tri,
-                                (const double *)obs->Mdev.p, (const double *)obs->shift.p,
-                                (const double *)obs->bias.p, make_epilogue(obs, flags), seed, step, first,
-                                count, a_out_dev, X_out_dev, w_out_dev, ctx->num_cus, ctx->stream));
-  return CUSMC_OK;
+  if (int rc = pf_step_prepare(obs, G, Q, y, F)) return rc;
+  return pf_step_launch(obs, kind, nu, w_prev_dev, X_prev_dev, N, B, scale, seed, step, first, count, a_out_dev,
+                        X_out_dev, w_out_dev, flags, (const double *)obs->shift.p, (const double *)obs->bias.p);
 }
 
 // First touch of freshly allocated host pages costs ~0.3 us per 4 KB page on one thread -- 0.2 s for
@@ -857,13 +886,14 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   if (int rc = cusmc_dist_create(ctx, kind, nullptr, V, d, df, &obs)) return rc;
 
   const size_t slice = (size_t)N * d;
-  DevBuf dX, dw, da;
+  DevBuf dX, dw, da, ytab;
+  std::vector<double> ytab_host;  // (alive until the stream is drained)
   int rc = dX.reserve(slice * T * 8);
   if (!rc) rc = dw.reserve((size_t)N * T * 8);
   if (!rc) rc = da.reserve((size_t)N * T * 4);
   auto cleanup = [&](int code) {
     (void)hipStreamSynchronize(ctx->stream);
-    dX.release(); dw.release(); da.release();
+    dX.release(); dw.release(); da.release(); ytab.release();
     cusmc_dist_destroy(obs);
     return code;
   };
@@ -883,11 +913,44 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
       return cleanup(fail(CUSMC_EHIP, "initial weight upload failed"));
   }
   // MCMC(): for t = 1..T-1: resample -> propagate -> reweight   src/mcmc.cpp:292-308
-  for (uint32_t t = 1; t < T; ++t) {
-    rc = cusmc_pf_step_dev(obs, kind, df, w + (size_t)(t - 1) * N, X + (size_t)(t - 1) * slice, N, G, Qw.data(),
-                           Y + (size_t)t * d, F, B, scale, seed, t, 0, N, a + (size_t)t * N,
-                           X + (size_t)t * slice, w + (size_t)t * N, CUSMC_OUT_DENSITY);
+  if (T > 1 && pf_step_is_fused(d, N)) {
+    // Small state: a time step is ONE launch, and for a small filter the per-step uploads of the
+    // observation (two 16..64-byte copies in the stream) would cost more than the launch.  All of Y is
+    // known here, so every step's shift (F = I: y_t) or bias (general F: W y_t) goes up in one
+    // table and the loop below is launches only.  Same values as the per-step plan, bit for bit.
+    rc = pf_step_prepare(obs, G, Qw.data(), Y + d, F);
     if (rc) return cleanup(rc);
+    const bool centred = obs->plan == 1;
+    ytab_host.assign((size_t)T * d, 0.0);
+    std::vector<double> b;
+    for (uint32_t t = 1; t < T; ++t) {
+      const double *y = Y + (size_t)t * d;
+      if (centred) {
+        std::copy(y, y + d, ytab_host.begin() + (size_t)t * d);
+      } else {
+        cusmc::la::matvec(obs->W.data(), y, d, b);
+        std::copy(b.begin(), b.end(), ytab_host.begin() + (size_t)t * d);
+      }
+    }
+    rc = ytab.reserve((size_t)T * d * 8);
+    if (rc) return cleanup(rc);
+    if (hipMemcpyAsync(ytab.p, ytab_host.data(), (size_t)T * d * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return cleanup(fail(CUSMC_EHIP, "observation table upload failed"));
+    const double *tab = (const double *)ytab.p;
+    for (uint32_t t = 1; t < T; ++t) {
+      rc = pf_step_launch(obs, kind, df, w + (size_t)(t - 1) * N, X + (size_t)(t - 1) * slice, N, B, scale, seed, t,
+                          0, N, a + (size_t)t * N, X + (size_t)t * slice, w + (size_t)t * N, CUSMC_OUT_DENSITY,
+                          centred ? tab + (size_t)t * d : (const double *)obs->shift.p,
+                          centred ? (const double *)obs->bias.p : tab + (size_t)t * d);
+      if (rc) return cleanup(rc);
+    }
+  } else {
+    for (uint32_t t = 1; t < T; ++t) {
+      rc = cusmc_pf_step_dev(obs, kind, df, w + (size_t)(t - 1) * N, X + (size_t)(t - 1) * slice, N, G, Qw.data(),
+                             Y + (size_t)t * d, F, B, scale, seed, t, 0, N, a + (size_t)t * N,
+                             X + (size_t)t * slice, w + (size_t)t * N, CUSMC_OUT_DENSITY);
+      if (rc) return cleanup(rc);
+    }
   }
   phase("enqueue of the time loop");
   // the loop above is only enqueued: fault the output pages in while it runs
