@@ -142,7 +142,9 @@ __device__ __forceinline__ double finish_epi(double q, const Epilogue &ep)
 // non-temporal output stores (+0.3 us) or particle loads (+1.4 us); spreading the next tile's loads
 // between the MFMAs with sched_group_barrier (+0.7 us); rotating each workgroup's slot from round to round, in case a
 // fixed slot pinned a workgroup to the same HBM channels (no effect: 94.4-95.2 us for rotations 0,
-// 1, 8, 37, 97 on one box).
+// 1, 8, 37, 97 on one box); giving every wave its first round by birth and an LDS-only barrier, so
+// that the factor loads and the first tile's loads are in flight together (+0.6 us: 96.0 -> 96.6
+// median over three interleaved runs, although the load-free variant gains 1 us).
 template <int NB>
 __host__ __device__ constexpr int mfma_threads()
 {

@@ -16,7 +16,7 @@
 
 using namespace cusmc;
 static constexpr int KT = mfma_threads<4>();  // launch shape of the kernel under test
-static constexpr size_t KLDS = (size_t)(32 * 4 + 4 + (mfma_factor_in_regs<4, true>() ? 0 : 40 * 64)) * 8;
+static constexpr size_t KLDS = (size_t)(32 * 4 + 4 + (mfma_factor_in_regs<4>() ? 0 : 40 * 64)) * 8;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -62,7 +62,7 @@ int main(int argc, char **argv)
     }
     std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
     printf("%s (%d threads, factor in %s): 15 x 200 launches: median %.1f min %.1f | no-loads median %.1f us\n", argv[1], KT,
-           mfma_factor_in_regs<4, true>() ? "VGPRs" : "LDS", a[7], a[0], b[7]);
+           mfma_factor_in_regs<4>() ? "VGPRs" : "LDS", a[7], a[0], b[7]);
     return 0;
   }
   {  // sustained vs isolated launches of the product variant at 2 blocks/CU
