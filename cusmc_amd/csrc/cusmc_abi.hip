@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -834,7 +835,8 @@ CUSMC_EXPORT int cusmc_pf_step_dev(cusmc_dist *obs, int kind, float nu, const do
 namespace {
 void prefault_async(std::vector<std::thread> &pool, void *p, size_t bytes, unsigned threads)
 {
-  if (!p || bytes < (64u << 20) || threads == 0) return;  // small outputs: not worth a thread
+  if (!p || bytes < (8u << 20) || threads == 0) return;  // small outputs: not worth a thread
+  threads = (unsigned)std::min<size_t>(threads, bytes / (4u << 20));  // >= 4 MB per thread
   const size_t page = 4096;
   const size_t pages = (bytes + page - 1) / page, per = (pages + threads - 1) / threads;
   for (unsigned t = 0; t < threads; ++t) {
@@ -888,14 +890,33 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   const size_t slice = (size_t)N * d;
   DevBuf dX, dw, da, ytab;
   std::vector<double> ytab_host;  // (alive until the stream is drained)
+  // The history goes back to the host in chunks of whole time steps WHILE the loop runs (the copy
+  // engine is idle otherwise and the 2.4 GB of BASELINE configs[2] take four times longer to
+  // cross PCIe than to compute): an event after the last step of each chunk, a second stream for
+  // the copies.  Small histories are one chunk.
+  const size_t step_bytes = slice * 8 + (size_t)N * 12;
+  const uint32_t chunk_steps = (size_t)T * step_bytes <= (128u << 20) ? T : (uint32_t)std::max<size_t>(1, (128u << 20) / step_bytes);
+  const uint32_t nchunks = (T + chunk_steps - 1) / chunk_steps;
+  std::vector<hipEvent_t> chunk_done(nchunks, nullptr);
+  hipStream_t copy_stream = nullptr;
   int rc = dX.reserve(slice * T * 8);
   if (!rc) rc = dw.reserve((size_t)N * T * 8);
   if (!rc) rc = da.reserve((size_t)N * T * 4);
   auto cleanup = [&](int code) {
     (void)hipStreamSynchronize(ctx->stream);
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+    for (hipEvent_t ev : chunk_done) if (ev) (void)hipEventDestroy(ev);
     dX.release(); dw.release(); da.release(); ytab.release();
     cusmc_dist_destroy(obs);
     return code;
+  };
+  // called when step t has been enqueued: closes a chunk after its last step
+  auto mark = [&](uint32_t t) -> int {
+    if (nchunks == 1 || ((t + 1) % chunk_steps != 0 && t + 1 != T)) return CUSMC_OK;
+    const uint32_t c = t / chunk_steps;
+    HIP_TRY(hipEventCreateWithFlags(&chunk_done[c], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(chunk_done[c], ctx->stream));
+    return CUSMC_OK;
   };
   if (rc) return cleanup(rc);
   phase("device allocation");
@@ -912,6 +933,8 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
         hipStreamSynchronize(ctx->stream) != hipSuccess)
       return cleanup(fail(CUSMC_EHIP, "initial weight upload failed"));
   }
+  rc = mark(0);
+  if (rc) return cleanup(rc);
   // MCMC(): for t = 1..T-1: resample -> propagate -> reweight   src/mcmc.cpp:292-308
   if (T > 1 && pf_step_is_fused(d, N)) {
     // Small state: a time step is ONE launch, and for a small filter the per-step uploads of the
@@ -942,6 +965,7 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
                           0, N, a + (size_t)t * N, X + (size_t)t * slice, w + (size_t)t * N, CUSMC_OUT_DENSITY,
                           centred ? tab + (size_t)t * d : (const double *)obs->shift.p,
                           centred ? (const double *)obs->bias.p : tab + (size_t)t * d);
+      if (!rc) rc = mark(t);
       if (rc) return cleanup(rc);
     }
   } else {
@@ -949,29 +973,69 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
       rc = cusmc_pf_step_dev(obs, kind, df, w + (size_t)(t - 1) * N, X + (size_t)(t - 1) * slice, N, G, Qw.data(),
                              Y + (size_t)t * d, F, B, scale, seed, t, 0, N, a + (size_t)t * N,
                              X + (size_t)t * slice, w + (size_t)t * N, CUSMC_OUT_DENSITY);
+      if (!rc) rc = mark(t);
       if (rc) return cleanup(rc);
     }
   }
   phase("enqueue of the time loop");
-  // the loop above is only enqueued: fault the output pages in while it runs
+  // The loop above is only enqueued: fault the output pages in with worker threads while it runs
+  // (the copies then go at PCIe speed), chunk by chunk, and copy each chunk out behind its event
+  // as soon as its pages are there.
   {
     unsigned hw = std::thread::hardware_concurrency();
     const unsigned threads = getenv("CUSMC_NO_PREFAULT") ? 0 : hw == 0 ? 4 : (hw > 16 ? 16 : hw);  // (switch: for A/B timing)
-    std::vector<std::thread> pool;
-    prefault_async(pool, X_out, slice * T * 8, threads);
-    prefault_async(pool, w_out, (size_t)N * T * 8, threads);
-    prefault_async(pool, a_out, (size_t)N * T * 4, threads);
-    for (auto &th : pool) th.join();
+    hipError_t e = hipSuccess;
+    if (nchunks == 1) {
+      std::vector<std::thread> pool;
+      prefault_async(pool, X_out, slice * T * 8, threads);
+      prefault_async(pool, w_out, (size_t)N * T * 8, threads);
+      prefault_async(pool, a_out, (size_t)N * T * 4, threads);
+      for (auto &th : pool) th.join();
+      if (X_out) e = hipMemcpyAsync(X_out, X, slice * T * 8, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess && w_out) e = hipMemcpyAsync(w_out, w, (size_t)N * T * 8, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess && a_out) e = hipMemcpyAsync(a_out, a, (size_t)N * T * 4, hipMemcpyDeviceToHost, ctx->stream);
+    } else {
+      // worker k touches its share of every chunk, in chunk order, and counts the chunk done
+      std::vector<std::atomic<unsigned>> ready(nchunks);
+      for (auto &r : ready) r.store(0, std::memory_order_relaxed);
+      auto touch = [](void *p, size_t bytes, unsigned k, unsigned n) {
+        if (!p) return;
+        const size_t page = 4096, pages = (bytes + page - 1) / page, per = (pages + n - 1) / n;
+        const size_t lo = (size_t)k * per, hi = std::min(pages, lo + per);
+        volatile char *c = static_cast<volatile char *>(p);
+        for (size_t g = lo; g < hi; ++g) c[g * page] = 0;
+      };
+      std::vector<std::thread> pool;
+      for (unsigned k = 0; k < threads; ++k)
+        pool.emplace_back([&, k] {
+          for (uint32_t c = 0; c < nchunks; ++c) {
+            const uint32_t t0 = c * chunk_steps, t1 = std::min<uint32_t>(T, t0 + chunk_steps);
+            touch(X_out ? X_out + (size_t)t0 * slice : nullptr, (size_t)(t1 - t0) * slice * 8, k, threads);
+            touch(w_out ? w_out + (size_t)t0 * N : nullptr, (size_t)(t1 - t0) * N * 8, k, threads);
+            touch(a_out ? a_out + (size_t)t0 * N : nullptr, (size_t)(t1 - t0) * N * 4, k, threads);
+            ready[c].fetch_add(1, std::memory_order_release);
+          }
+        });
+      e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+      for (uint32_t c = 0; c < nchunks && e == hipSuccess; ++c) {
+        while (ready[c].load(std::memory_order_acquire) < threads) std::this_thread::yield();
+        const uint32_t t0 = c * chunk_steps, t1 = std::min<uint32_t>(T, t0 + chunk_steps);
+        const size_t steps = t1 - t0;
+        e = hipStreamWaitEvent(copy_stream, chunk_done[c], 0);
+        if (e == hipSuccess && X_out)
+          e = hipMemcpyAsync(X_out + (size_t)t0 * slice, X + (size_t)t0 * slice, steps * slice * 8, hipMemcpyDeviceToHost, copy_stream);
+        if (e == hipSuccess && w_out)
+          e = hipMemcpyAsync(w_out + (size_t)t0 * N, w + (size_t)t0 * N, steps * N * 8, hipMemcpyDeviceToHost, copy_stream);
+        if (e == hipSuccess && a_out)
+          e = hipMemcpyAsync(a_out + (size_t)t0 * N, a + (size_t)t0 * N, steps * N * 4, hipMemcpyDeviceToHost, copy_stream);
+      }
+      for (auto &th : pool) th.join();
+      if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return cleanup(fail(CUSMC_EHIP, "%s copying filter outputs", hipGetErrorString(e)));
   }
-  phase("output pages faulted in");
-  if (trace) { (void)hipStreamSynchronize(ctx->stream); phase("time loop finished on the GPU"); }
-  hipError_t e = hipSuccess;
-  if (X_out) e = hipMemcpyAsync(X_out, X, slice * T * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess && w_out) e = hipMemcpyAsync(w_out, w, (size_t)N * T * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess && a_out) e = hipMemcpyAsync(a_out, a, (size_t)N * T * 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) return cleanup(fail(CUSMC_EHIP, "%s copying filter outputs", hipGetErrorString(e)));
-  phase("device-to-host copies");
+  phase("page faults + device-to-host copies (overlapping the loop)");
   const int done = cleanup(CUSMC_OK);
   phase("device memory released");
   return done;
