@@ -2,13 +2,14 @@
 """Times the per-GPU share of every BASELINE.json config on one MI355X (device-resident inputs,
 HIP events on the launch stream) and prints a markdown table for BASELINE.md section 4.
 Not the judged bench (that is bench.py); these are the parity-test shapes, timed."""
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd  # noqa: E402
 
 
@@ -51,6 +52,19 @@ def main():
         flops = N / 16 * 2 * nb * (nb + 1) * 2048 if d % 16 == 0 else N * (d * d + 4 * d)
         rows.append((name, "%.3g evals/s" % (N / t), "%.1f us" % (t * 1e6), "%.2f TB/s" % (N * (8 * d + 8) / t / 1e12),
                      "%.1f TFLOP/s" % (flops / t / 1e12)))
+        D.close()
+        del X, out
+    # reweight_G with a general (dense) observation matrix F: QL-rotated on the host to the triangular form
+    for name, N, d in (("reweight 1e6 x d=64, dense F", 1_000_000, 64), ("reweight 5e5 x d=256, dense F", 500_000, 256)):
+        X = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+        out = torch.empty(N, dtype=torch.float64, device="cuda")
+        D = cusmc_amd.MultiVariateNormalDistribution(np.zeros(d), spd(d, 1), ctx=ctx)
+        F = np.eye(d) + 0.3 * np.random.default_rng(2).standard_normal((d, d)) / np.sqrt(d)
+        y = np.ones(d)
+        t = timed(lambda: D.reweight_dev(X, y, F, out), 200 if d == 64 else 50, 200)
+        nb = d // 16
+        rows.append((name, "%.3g evals/s" % (N / t), "%.1f us" % (t * 1e6), "%.2f TB/s" % (N * (8 * d + 8) / t / 1e12),
+                     "%.1f TFLOP/s" % (N / 16 * 2 * nb * (nb + 1) * 2048 / t / 1e12)))
         D.close()
         del X, out
     # resampler shapes

@@ -5,6 +5,8 @@
 //   hipcc --offload-arch=gfx950 /tmp/ablate.o cusmc_amd/csrc/build/kernels/logpdf_mfma.o -o scripts/calib/ablate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
+#include <cmath>
 #include <time.h>
 #include <vector>
 #include <algorithm>
@@ -52,6 +54,47 @@ int main(int argc, char **argv)
   CK(hipMemcpy(X, hX.data(), hX.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(F, frags.data(), frags.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(sh, z.data(), 512, hipMemcpyHostToDevice)); CK(hipMemcpy(bi, z.data(), 512, hipMemcpyHostToDevice));
+  if (argc > 1 && !strcmp(argv[1], "persist")) {
+    // Are slow workgroups the same ones from launch to launch?  Per-workgroup end times (last wave,
+    // 100 MHz stamps) of 8 stamped launches inside a sustained run, and their rank correlation.
+    Epilogue ep{-10.0, 0, 0, 0, 0};
+    const long tiles = (N + 15) / 16;
+    const int L = 8;
+    std::vector<std::vector<double>> wg(L, std::vector<double>(256));
+    for (int l = 0; l < L; ++l) {
+      for (int i = 0; i < 100; ++i)
+        hipLaunchKernelGGL((logpdf_mfma_kernel<4, true, false, 4, 1>), dim3(256), dim3(KT), KLDS, 0, X, N, 64L, F, sh, bi, ep, out, tiles);
+      CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> ab(3 * 2048);
+      CK(hipMemcpy(ab.data(), out + tiles * 16 + 3 * 2048, ab.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long e0 = ~0ULL; for (int w = 0; w < 2048; ++w) e0 = std::min(e0, ab[3 * w]);
+      for (int b = 0; b < 256; ++b) { double m = 0; for (int w = 0; w < 8; ++w) m = std::max(m, (ab[3 * (8 * b + w) + 2] - e0) / 100.0); wg[l][b] = m; }
+    }
+    double mean[256] = {0};
+    for (int l = 0; l < L; ++l) for (int b = 0; b < 256; ++b) mean[b] += wg[l][b] / L;
+    auto corr = [&](const std::vector<double> &a, const std::vector<double> &b) {
+      double ma = 0, mb = 0; for (int i = 0; i < 256; ++i) { ma += a[i] / 256; mb += b[i] / 256; }
+      double sab = 0, saa = 0, sbb = 0; for (int i = 0; i < 256; ++i) { sab += (a[i] - ma) * (b[i] - mb); saa += (a[i] - ma) * (a[i] - ma); sbb += (b[i] - mb) * (b[i] - mb); }
+      return sab / std::sqrt(saa * sbb);
+    };
+    double c = 0; int nc = 0;
+    for (int i = 0; i < L; ++i) for (int j = i + 1; j < L; ++j) { c += corr(wg[i], wg[j]); ++nc; }
+    printf("mean pairwise correlation of per-workgroup end times over %d launches: %.3f\n", L, c / nc);
+    for (int l = 0; l < L; ++l) {
+      std::vector<double> s = wg[l]; std::sort(s.begin(), s.end());
+      int amax = 0; for (int b = 0; b < 256; ++b) if (wg[l][b] > wg[l][amax]) amax = b;
+      printf("launch %d: end min %.1f p50 %.1f p90 %.1f max %.1f (slowest workgroup %d)\n", l, s[0], s[128], s[230], s[255], amax);
+    }
+    std::vector<int> idx(256); for (int i = 0; i < 256; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return mean[a] > mean[b]; });
+    printf("slowest on average:"); for (int i = 0; i < 12; ++i) printf(" %d(%.1f)", idx[i], mean[idx[i]]); printf("\nfastest on average:");
+    for (int i = 255; i > 243; --i) printf(" %d(%.1f)", idx[i], mean[idx[i]]); printf("\n");
+    double byx[8] = {0}; for (int b = 0; b < 256; ++b) byx[b % 8] += mean[b] / 32;
+    printf("mean end by workgroup %% 8:"); for (int i = 0; i < 8; ++i) printf(" %.1f", byx[i]); printf("\n");
+    double by32[8] = {0}; for (int b = 0; b < 256; ++b) by32[b / 32] += mean[b] / 32;
+    printf("mean end by workgroup / 32:"); for (int i = 0; i < 8; ++i) printf(" %.1f", by32[i]); printf("\n");
+    return 0;
+  }
   if (argc > 1) {  // quick mode: sustained timing of the product variant only (for A/B between builds)
     std::vector<float> a;
     run<0>(X, N, F, sh, bi, out, 256, 600);

@@ -1,7 +1,8 @@
 """Log-pdf timings at dimensions that are NOT multiples of 16 (padded MFMA variants; d < 16 generic).
 Developer aid:  python scripts/generic_sweep.py"""
+import os
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd
 from scripts.logpdf_sweep import spd, timed
 ctx = cusmc_amd.api.default_context().use_torch_stream()

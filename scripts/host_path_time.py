@@ -1,6 +1,7 @@
 """PCIe-inclusive rate of the host-pointer entry points (what the R-level API pays).  Developer aid."""
+import os
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd
 from scripts.logpdf_sweep import spd
 N, d = 1_000_000, 64

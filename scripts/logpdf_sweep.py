@@ -2,12 +2,13 @@
 """Times the log-pdf kernels over d and distribution kind on one MI355X (device-resident X, HIP
 events on the launch stream).  Developer aid for A/B runs between library builds:
     python scripts/logpdf_sweep.py [tag]"""
+import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd  # noqa: E402
 
 

@@ -1,5 +1,6 @@
+import os
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd
 cusmc_amd.set_seed(1)
 N, d, T = 1_000_000, 2, 20

@@ -1,5 +1,6 @@
+import os
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd, torch
 cusmc_amd.set_seed(1)
 for (N, d, T) in [(1_000_000, 2, 100), (1_000_000, 8, 20), (200_000, 64, 10)]:

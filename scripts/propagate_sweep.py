@@ -1,6 +1,7 @@
 """Proposal-draw timings with DENSE G and Q over d (1e6*64/d particles).  Developer aid."""
+import os
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd
 from scripts.logpdf_sweep import timed
 ctx = cusmc_amd.api.default_context().use_torch_stream()

@@ -1,6 +1,7 @@
 """Phase timing of cusmc_pf_run_host (CUSMC_TRACE=1 prints the phases to stderr).  Developer aid."""
+import os
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd
 for (N, d, T) in [(1_000_000, 2, 100), (1_000_000, 8, 20), (200_000, 64, 10)]:
     I = np.eye(d)

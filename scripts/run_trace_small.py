@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Phase timing of run() for a small filter (CUSMC_TRACE=1 prints the phases of cusmc_pf_run_host).
     CUSMC_TRACE=1 python scripts/run_trace_small.py [N] [T]"""
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000

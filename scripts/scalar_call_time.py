@@ -1,6 +1,7 @@
 """Latency of the R-level scalar calls (one density / one draw / one small resample).  Developer aid."""
+import os
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd
 from scripts.logpdf_sweep import spd
 for d in (2, 8, 64, 256):

@@ -1,6 +1,7 @@
 """Shifted-form (mu != 0) log-pdf timings over d for A/B between library builds.  Developer aid."""
+import os
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd
 from scripts.logpdf_sweep import spd, timed
 tag = sys.argv[1]

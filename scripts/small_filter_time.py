@@ -1,6 +1,7 @@
 """run() wall time for small filters (launch- and upload-bound regime).  Developer aid."""
+import os
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd
 cusmc_amd.set_seed(1)
 for (N, d, T) in [(1000, 2, 100), (10_000, 2, 100), (100_000, 2, 100), (1000, 8, 100), (1000, 32, 100)]:

@@ -20,6 +20,14 @@ def main(d):
                 continue
             print("| %s | %s | %.1f | %.1f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                            float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    for f in glob.glob(d + "/configs/**/*kernel_stats.csv", recursive=True):
+        print("\n## --kernel-trace --stats (python3 scripts/bench_configs.py: the other BASELINE configs)\n")
+        print("| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|")
+        for r in csv.DictReader(open(f)):
+            if "cusmc::" not in r["Name"]:
+                continue
+            print("| %s | %s | %.1f | %.1f | %.1f |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                      float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(d + "/%s/**/*counter_collection.csv" % counter.split("_")[0].lower(), recursive=True):
             vals = {}

@@ -1,5 +1,6 @@
+import os
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cusmc_amd
 ctx = cusmc_amd.api.default_context().use_torch_stream()
 for N, d in ((500_000, 256), (1_000_000, 128), (1_000_000, 64)):
