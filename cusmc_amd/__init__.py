@@ -11,5 +11,5 @@ The compute lives in the shared library only; nothing here falls back to numpy o
 """
 from ._lib import SO_PATH, CusmcError  # noqa: F401
 from .api import (MVN, MVNPDF, MVT, MVTPDF, Context, MultiVariateNormalDistribution,  # noqa: F401
-                  MultiVariateTStudentDistribution, Sampler, eigenSolver, metropolis_hastings,
-                  run, set_seed)
+                  MultiVariateTStudentDistribution, Sampler, cholesky_batched, eigenSolver,
+                  logpdf_percov, metropolis_hastings, run, set_seed)

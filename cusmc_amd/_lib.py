@@ -45,6 +45,10 @@ SYMBOLS = [
     ("cusmc_initialize_dev", _i, [_vp, _i, _f, _vp, _vp, _i, _d, _u64, _u32, _u32, _vp]),
     ("cusmc_sample_host", _i, [_vp, _i, _f, _vp, _vp, _i, _d, _u64, _u32, _u32, _vp]),
     ("cusmc_eigen_sqrt", _i, [_vp, _i, _vp]),
+    ("cusmc_chol_batched_dev", _i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    ("cusmc_chol_batched_host", _i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    ("cusmc_logpdf_percov_dev", _i, [_vp, _i, _f, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i, _vp, _vp]),
+    ("cusmc_logpdf_percov_host", _i, [_vp, _i, _f, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i, _vp, _vp]),
     ("cusmc_pf_step_dev", _i, [_vp, _i, _f, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _d, _u64, _u32, _u32,
                                _u32, _vp, _vp, _vp, _i]),
     ("cusmc_pf_run_host", _i, [_vp, _vp, _u32, _i, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _f,

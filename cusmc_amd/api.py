@@ -28,7 +28,7 @@ from ._lib import MVN as _MVN, MVT as _MVT, OUT_DENSITY, OUT_LOG, CusmcError, ch
 
 __all__ = ["Context", "MultiVariateNormalDistribution", "MultiVariateTStudentDistribution",
            "Sampler", "propagate_dev", "initialize_dev", "MVN", "MVNPDF", "MVT", "MVTPDF", "metropolis_hastings", "run",
-           "set_seed", "eigenSolver", "CusmcError"]
+           "set_seed", "eigenSolver", "cholesky_batched", "logpdf_percov", "CusmcError"]
 
 SQRT3 = 1.7320508075688772  # the reference CPU transform's std-dev inflation
 
@@ -111,6 +111,43 @@ def eigenSolver(sigma):
     Q = np.empty_like(sigma)
     check(_lib.lib().cusmc_eigen_sqrt(_ptr(sigma), sigma.shape[0], _ptr(Q)))
     return Q
+
+
+def cholesky_batched(sigma, ctx=None):
+    """Cholesky factors of N small covariances at once (d <= 16).
+    sigma: N x d x d.  Returns (L, logdet, info): L N x d x d lower triangular, logdet N, info N
+    (0, or 1 + the index of the first non-positive pivot)."""
+    ctx = ctx or default_context()
+    sigma = _f64(sigma)
+    if sigma.ndim != 3 or sigma.shape[1] != sigma.shape[2]:
+        raise ValueError("sigma must be N x d x d")
+    N, d = sigma.shape[0], sigma.shape[1]
+    L, logdet, info = np.empty_like(sigma), np.empty(N), np.empty(N, dtype=np.int32)
+    check(_lib.lib().cusmc_chol_batched_host(ctx._h, _ptr(sigma), N, d, _ptr(L), _ptr(logdet), _ptr(info)))
+    return L, logdet, info
+
+
+def logpdf_percov(X, mu, sigma, nu=None, log=True, ctx=None):
+    """log p(X[i]; mu[i], sigma[i]) with a covariance PER PARTICLE (d <= 16): multivariate Normal,
+    or Student-t when nu is given.  X: N x d; mu: None, a d-vector or N x d; sigma: N x d x d.
+    Returns (values, info)."""
+    ctx = ctx or default_context()
+    X, sigma = _f64(X), _f64(sigma)
+    N, d = X.shape
+    if sigma.shape != (N, d, d):
+        raise ValueError("sigma must be N x d x d")
+    ldmu = 0
+    if mu is not None:
+        mu = _f64(mu)
+        if mu.shape == (N, d) and mu.ndim == 2:
+            ldmu = d
+        elif mu.shape != (d,):
+            raise ValueError("mu must be None, a d-vector or N x d")
+    out, info = np.empty(N), np.empty(N, dtype=np.int32)
+    check(_lib.lib().cusmc_logpdf_percov_host(ctx._h, _MVN if nu is None else _MVT, 0.0 if nu is None else float(nu),
+                                              _ptr(X), N, d, None if mu is None else _ptr(mu), ldmu, _ptr(sigma), d,
+                                              _lib.OUT_LOG if log else _lib.OUT_DENSITY, _ptr(out), _ptr(info)))
+    return out, info
 
 
 class _Distribution:

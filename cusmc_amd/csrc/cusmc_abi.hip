@@ -738,6 +738,122 @@ CUSMC_EXPORT int cusmc_eigen_sqrt(const double *sigma, int d, double *Q)
 
 // ---- one filter time step -------------------------------------------------------------------
 
+// ---- per-particle covariances ------------------------------------------------------------------
+
+namespace {
+
+int percov_epilogue(int kind, float nu, int d, int flags, Epilogue *ep)
+{
+  if (kind != CUSMC_MVN && kind != CUSMC_MVT) return fail(CUSMC_EINVAL, "unknown distribution kind %d", kind);
+  if (kind == CUSMC_MVT && !(nu > 0.f)) return fail(CUSMC_EINVAL, "nu = %g must be positive", (double)nu);
+  const double pi = 3.14159265358979323846;
+  const float nu_plus_d = nu + (float)d;  // float arithmetic, as the reference (statistics.cc.cpp:332-340)
+  ep->kind = kind;
+  ep->out_density = (flags & CUSMC_OUT_DENSITY) ? 1 : 0;
+  ep->half_nu_plus_d = 0.5 * (double)nu_plus_d;
+  ep->inv_nu = kind == CUSMC_MVT ? 1.0 / (double)nu : 0.0;
+  // the normalising constants of cusmc_dist_create() without their determinant term
+  ep->lognorm = kind == CUSMC_MVN ? -0.5 * (double)d * std::log(2.0 * pi)
+                                  : std::lgamma(0.5 * (double)nu_plus_d) - std::lgamma(0.5 * (double)nu) -
+                                        0.5 * (double)d * std::log(pi * (double)nu);
+  return CUSMC_OK;
+}
+
+int percov_check(int64_t N, int d)
+{
+  if (N < 0) return fail(CUSMC_EINVAL, "N = %lld is negative", (long long)N);
+  if (!cusmc::percov_supported(d))
+    return fail(CUSMC_ERANGE, "per-particle covariances are served for 1 <= d <= 16 (d = %d)", d);
+  return CUSMC_OK;
+}
+
+}  // namespace
+
+CUSMC_EXPORT int cusmc_chol_batched_dev(cusmc_ctx *ctx, const double *sigma_dev, int64_t N, int d,
+                                        double *L_dev, double *logdet_dev, int32_t *info_dev)
+{
+  if (int rc = activate(ctx)) return rc;
+  if (int rc = percov_check(N, d)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (!sigma_dev || !L_dev) return fail(CUSMC_EINVAL, "null sigma or L pointer");
+  HIP_TRY(cusmc::launch_cholesky_batched(sigma_dev, N, d, L_dev, logdet_dev, info_dev, ctx->num_cus, ctx->stream));
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_chol_batched_host(cusmc_ctx *ctx, const double *sigma, int64_t N, int d, double *L,
+                                         double *logdet, int32_t *info)
+{
+  if (int rc = activate(ctx)) return rc;
+  if (int rc = percov_check(N, d)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (!sigma || !L) return fail(CUSMC_EINVAL, "null sigma or L pointer");
+  const size_t mbytes = (size_t)N * d * d * 8;
+  if (int rc = ctx->scratch[0].reserve(mbytes)) return rc;
+  if (int rc = ctx->scratch[4].reserve(mbytes)) return rc;
+  if (int rc = ctx->scratch[1].reserve((size_t)N * 8)) return rc;
+  if (int rc = ctx->scratch[3].reserve((size_t)N * 4)) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->scratch[0].p, sigma, mbytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(cusmc::launch_cholesky_batched((const double *)ctx->scratch[0].p, N, d, (double *)ctx->scratch[4].p,
+                                         (double *)ctx->scratch[1].p, (int *)ctx->scratch[3].p, ctx->num_cus,
+                                         ctx->stream));
+  HIP_TRY(hipMemcpyAsync(L, ctx->scratch[4].p, mbytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (logdet) HIP_TRY(hipMemcpyAsync(logdet, ctx->scratch[1].p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (info) HIP_TRY(hipMemcpyAsync(info, ctx->scratch[3].p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_logpdf_percov_dev(cusmc_ctx *ctx, int kind, float nu, const double *X_dev, int64_t N,
+                                         int64_t ldx, const double *mu_dev, int64_t ldmu,
+                                         const double *sigma_dev, int d, int flags, double *out_dev,
+                                         int32_t *info_dev)
+{
+  if (int rc = activate(ctx)) return rc;
+  if (int rc = percov_check(N, d)) return rc;
+  Epilogue ep;
+  if (int rc = percov_epilogue(kind, nu, d, flags, &ep)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (!X_dev || !sigma_dev || !out_dev) return fail(CUSMC_EINVAL, "null batch, sigma or output pointer");
+  if (ldx < d) return fail(CUSMC_EINVAL, "ldx = %lld < d = %d", (long long)ldx, d);
+  if (mu_dev && ldmu != 0 && ldmu < d) return fail(CUSMC_EINVAL, "ldmu = %lld is neither 0 nor >= d = %d", (long long)ldmu, d);
+  HIP_TRY(cusmc::launch_logpdf_percov(X_dev, N, ldx, mu_dev, ldmu, sigma_dev, d, ep, out_dev, info_dev, ctx->num_cus,
+                                      ctx->stream));
+  return CUSMC_OK;
+}
+
+CUSMC_EXPORT int cusmc_logpdf_percov_host(cusmc_ctx *ctx, int kind, float nu, const double *X, int64_t N,
+                                          int64_t ldx, const double *mu, int64_t ldmu, const double *sigma,
+                                          int d, int flags, double *out, int32_t *info)
+{
+  if (int rc = activate(ctx)) return rc;
+  if (int rc = percov_check(N, d)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (!X || !sigma || !out) return fail(CUSMC_EINVAL, "null batch, sigma or output pointer");
+  if (ldx < d) return fail(CUSMC_EINVAL, "ldx = %lld < d = %d", (long long)ldx, d);
+  if (mu && ldmu != 0 && ldmu < d) return fail(CUSMC_EINVAL, "ldmu = %lld is neither 0 nor >= d = %d", (long long)ldmu, d);
+  const size_t xbytes = ((size_t)(N - 1) * ldx + d) * 8, mbytes = (size_t)N * d * d * 8;
+  const size_t mubytes = !mu ? 0 : ldmu == 0 ? (size_t)d * 8 : ((size_t)(N - 1) * ldmu + d) * 8;
+  if (int rc = ctx->scratch[0].reserve(xbytes)) return rc;
+  if (int rc = ctx->scratch[4].reserve(mbytes)) return rc;
+  if (int rc = ctx->scratch[1].reserve((size_t)N * 8)) return rc;
+  if (int rc = ctx->scratch[3].reserve((size_t)N * 4)) return rc;
+  if (mubytes) {
+    if (int rc = ctx->scratch[5].reserve(mubytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->scratch[5].p, mu, mubytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->scratch[0].p, X, xbytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->scratch[4].p, sigma, mbytes, hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = cusmc_logpdf_percov_dev(ctx, kind, nu, (const double *)ctx->scratch[0].p, N, ldx,
+                                       mubytes ? (const double *)ctx->scratch[5].p : nullptr, ldmu,
+                                       (const double *)ctx->scratch[4].p, d, flags, (double *)ctx->scratch[1].p,
+                                       (int32_t *)ctx->scratch[3].p))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(out, ctx->scratch[1].p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (info) HIP_TRY(hipMemcpyAsync(info, ctx->scratch[3].p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSMC_OK;
+}
+
 // ---- fused filter step (d <= 8): host-side pieces --------------------------------------------------
 namespace {
 

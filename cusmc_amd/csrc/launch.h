@@ -107,4 +107,13 @@ hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const uint32
                           uint32_t first, uint32_t count, uint32_t *a_out, double *X_out,
                           double *w_out, int num_cus, hipStream_t stream);
 
+// --- kernels/percov.hip : per-particle covariances, d <= 16 (lane = matrix, triangle in LDS) -------
+bool percov_supported(int d);
+hipError_t launch_cholesky_batched(const double *S, int64_t N, int d, double *L, double *logdet, int *info,
+                                   int num_cus, hipStream_t stream);
+// ep.lognorm: the normalising constant without the determinant term (-logdet_i / 2 is added per particle)
+hipError_t launch_logpdf_percov(const double *X, int64_t N, int64_t ldx, const double *mu, int64_t ldmu,
+                                const double *S, int d, const Epilogue &ep, double *out, int *info, int num_cus,
+                                hipStream_t stream);
+
 }  // namespace cusmc

@@ -160,6 +160,31 @@ int cusmc_sample_host(cusmc_ctx *ctx, int kind, float nu, const double *mu, cons
 /* eigenSolver -- src/linear_algebra.cpp:10-23:  Q = V sqrt(Lambda), Q Q^T = sigma.  Host only. */
 int cusmc_eigen_sqrt(const double *sigma, int d, double *Q);
 
+/* ---- per-particle covariances (d <= 16) -- SURVEY.md 8(f) row 4 --------------------------------
+ * The reference has one covariance per distribution object (distParams_t, inst/include/
+ * statistics.hpp:22-34) but factors it inside every pdf() call (Sigma.determinant() and
+ * Sigma.inverse(), src/statistics.cc.cpp:176-177, 301, 306); these entry points serve models whose
+ * covariance differs from particle to particle.  sigma: N matrices, d x d row-major, back to back
+ * (only the lower triangles are read).
+ *   cusmc_chol_batched_*:   L[i] = lower Cholesky factor (upper part zeroed), logdet[i] = log det
+ *                           Sigma_i, info[i] = 0 or 1 + the index of the first non-positive pivot
+ *                           (L[i] and logdet[i] are then not finite).  logdet / info may be NULL.
+ *   cusmc_logpdf_percov_*:  out[i] = log p(X[i,:]; mu_i, Sigma_i) -- multivariate Normal, or
+ *                           Student-t with nu degrees of freedom (float, as the reference's nu);
+ *                           mu: N x ldmu, or ONE shared d-vector when ldmu == 0, or NULL (zero).
+ *                           flags as above; NaN where Sigma_i is not positive definite. */
+int cusmc_chol_batched_dev(cusmc_ctx *ctx, const double *sigma_dev, int64_t N, int d, double *L_dev,
+                           double *logdet_dev, int32_t *info_dev);
+int cusmc_chol_batched_host(cusmc_ctx *ctx, const double *sigma, int64_t N, int d, double *L,
+                            double *logdet, int32_t *info);
+int cusmc_logpdf_percov_dev(cusmc_ctx *ctx, int kind, float nu, const double *X_dev, int64_t N,
+                            int64_t ldx, const double *mu_dev, int64_t ldmu,
+                            const double *sigma_dev, int d, int flags, double *out_dev,
+                            int32_t *info_dev);
+int cusmc_logpdf_percov_host(cusmc_ctx *ctx, int kind, float nu, const double *X, int64_t N,
+                             int64_t ldx, const double *mu, int64_t ldmu, const double *sigma, int d,
+                             int flags, double *out, int32_t *info);
+
 /* ---- one filter time step: the body of MCMC()'s loop -- src/mcmc.cpp:292-308 -----------------
  *     a[i]   = Metropolis chain i over w_prev                 (cusmc_metropolis_dev)
  *     x_t[i] = [diag(c_i)] Q (scale * xi_i) + G x_prev[a[i]]  (cusmc_propagate_dev, kind/nu of the proposal)

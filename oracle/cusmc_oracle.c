@@ -202,6 +202,55 @@ ORACLE_API void oracle_pdf_batch(const double *X, long N, long ldx, const double
   }
 }
 
+/* Per-particle covariances: the reference's own pdf() -- which factors the
+ * covariance of its distribution object on every call anyway (src/statistics.cc.cpp:176-177, 301,
+ * 306) -- applied with a distribution object PER PARTICLE: mu_i (mu + i*ldmu; ldmu == 0: one shared
+ * vector; mu == NULL: zero) and sigma_i (sigma + i*n*n).  Densities, like pdf(). */
+ORACLE_API void oracle_pdf_percov(const double *X, long N, long ldx, const double *mu, long ldmu,
+                                  const double *sigma, int n, int dist, float nu, double *out)
+{
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < N; ++i) {
+    /* the pdf(y) overload takes the residual itself (it ignores the object's mu: :171-180) */
+    double *r = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int a = 0; a < n; ++a) r[a] = X[i * ldx + a] - (mu ? mu[i * ldmu + a] : 0.0);
+    const double *S = sigma + i * (long)n * n;
+    out[i] = dist ? oracle_mvt_pdf(r, NULL, S, NULL, n, nu) : oracle_mvn_pdf(r, NULL, S, NULL, n);
+    free(r);
+  }
+}
+
+/* Batched Cholesky, operation for operation what cusmc_amd/csrc/kernels/percov.hip does (row by
+ * row, fma chains in index order, one sqrt and one divide per element), so the factors can be
+ * compared bit for bit; logdet through libm's log.  info[i] = 0 or 1 + the first bad pivot. */
+ORACLE_API void oracle_chol_batched(const double *sigma, long N, int n, double *L, double *logdet, int *info)
+{
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < N; ++i) {
+    const double *S = sigma + i * (long)n * n;
+    double *l = L + i * (long)n * n;
+    int bad = 0;
+    double ld = 0.0;
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) l[r * n + c] = c <= r ? S[r * n + c] : 0.0;
+    for (int j = 0; j < n; ++j) {
+      double sum = l[j * n + j];
+      for (int k = 0; k < j; ++k) sum = fma(-l[j * n + k], l[j * n + k], sum);
+      if (!(sum > 0.0) && bad == 0) bad = j + 1;
+      const double ljj = sqrt(sum);
+      l[j * n + j] = ljj;
+      ld += log(ljj);
+      for (int r = j + 1; r < n; ++r) {
+        double t = l[r * n + j];
+        for (int k = 0; k < j; ++k) t = fma(-l[r * n + k], l[j * n + k], t);
+        l[r * n + j] = t / ljj;
+      }
+    }
+    if (logdet) logdet[i] = bad ? NAN : 2.0 * ld;
+    if (info) info[i] = bad;
+  }
+}
+
 /* reweight_G, CPU branch -- src/mcmc.cpp:185-215:
  *   w[i] = pdf_{0,V}( y - F * x_i )     (the pdf(y) overload, mean zero) */
 ORACLE_API void oracle_reweight(const double *X, long N, long ldx, const double *y,

@@ -163,6 +163,29 @@ def exp_nonpos(t):
     return f(C.c_double(t))
 
 
+def pdf_percov(X, mu, sigma, dist="mvn", nu=0.0):
+    """The reference's pdf() with a distribution object per particle (densities)."""
+    X, sigma = _d(X), _d(sigma)
+    N, d = X.shape
+    ldmu = 0
+    if mu is not None:
+        mu = _d(mu)
+        ldmu = d if mu.ndim == 2 else 0
+    out = np.empty(N)
+    lib().oracle_pdf_percov(_p(X), C.c_long(N), C.c_long(d), None if mu is None else _p(mu), C.c_long(ldmu),
+                            _p(sigma), C.c_int(d), C.c_int(0 if dist == "mvn" else 1), C.c_float(nu), _p(out))
+    return out
+
+
+def chol_batched(sigma):
+    """Batched Cholesky in the kernels' operation order: (L, logdet, info)."""
+    sigma = _d(sigma)
+    N, d = sigma.shape[0], sigma.shape[1]
+    L, logdet, info = np.empty_like(sigma), np.empty(N), np.empty(N, dtype=np.int32)
+    lib().oracle_chol_batched(_p(sigma), C.c_long(N), C.c_int(d), _p(L), _p(logdet), _p(info))
+    return L, logdet, info
+
+
 def eigen_sqrt(S):
     S = _d(S)
     Q = np.empty_like(S)

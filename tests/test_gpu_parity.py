@@ -785,3 +785,63 @@ def test_sharded_filter_on_gpu_equals_run(cs, tmp_path, N, d):
     assert np.array_equal(got["a"][1:], res["ancestors"][1:].astype(got["a"].dtype))
     assert np.array_equal(got["X"], res["posterior_x"])
     assert np.array_equal(got["w"], res["weights"])
+
+
+# --- per-particle covariances ---------------------------------------------
+
+def _random_covariances(rng, N, d):
+    A = rng.standard_normal((N, d, d))
+    scale = np.exp(rng.uniform(-2, 2, size=(N, 1, 1)))
+    return scale * (A @ np.transpose(A, (0, 2, 1)) / d + np.eye(d))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 11, 16])
+def test_batched_cholesky_bit_exact(cs, oracle, d):
+    """cusmc_chol_batched_host against the oracle's restatement of the same operation order:
+    factors bit for bit (fma chains, one sqrt, one divide per element), log-determinants to the
+    last bits of two different ln, the pivot report for matrices that are not positive definite."""
+    rng = np.random.default_rng(300 + d)
+    N = 1000 + d  # not a multiple of the 64-lane workgroup
+    S = _random_covariances(rng, N, d)
+    bad = [0, 17, N - 1]
+    for n, i in enumerate(bad):
+        S[i] = np.eye(d)
+        S[i][min(n, d - 1), min(n, d - 1)] = -2.0 if n else 0.0
+    L, logdet, info = cs.api.cholesky_batched(S)
+    Lo, ldo, io = oracle.chol_batched(S)
+    assert np.array_equal(info, io)
+    assert info[bad[0]] == 1 and set(np.flatnonzero(info)) == set(bad)
+    good = info == 0
+    assert np.array_equal(L[good], Lo[good])
+    assert np.all(np.triu(L[good], 1) == 0.0)
+    assert np.allclose(logdet[good], ldo[good], rtol=1e-14, atol=1e-13)
+    assert np.all(np.isnan(logdet[~good]))
+    with pytest.raises(cs.CusmcError):
+        cs.api.cholesky_batched(np.tile(np.eye(17), (3, 1, 1)))
+    assert cs.api.cholesky_batched(np.empty((0, d, d)))[0].shape == (0, d, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [1, 2, 4, 8, 13, 16])
+@pytest.mark.parametrize("dist", ["mvn", "mvt"])
+def test_logpdf_per_particle_covariance(cs, oracle, d, dist):
+    """cusmc_logpdf_percov_host against the reference's pdf() applied with a distribution object
+    per particle (oracle.pdf_percov: LU determinant + inverse per particle), tolerance 1e-6 relative
+    on the log-density as for the shared-covariance kernels; means per particle, shared, or absent."""
+    rng = np.random.default_rng(400 + d)
+    N = 777
+    S = _random_covariances(rng, N, d)
+    X = rng.standard_normal((N, d))
+    nu = None if dist == "mvn" else 4.0
+    for mu in (rng.standard_normal((N, d)), rng.standard_normal(d), None):
+        lp, info = cs.api.logpdf_percov(X, mu, S, nu=nu)
+        assert not info.any()
+        want = np.log(oracle.pdf_percov(X, mu, S, dist=dist, nu=nu or 0.0))
+        assert rel_err(lp, want) < RTOL
+        assert np.abs(lp - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+    dens, _ = cs.api.logpdf_percov(X, None, S, nu=nu, log=False)
+    assert rel_err(dens, oracle.pdf_percov(X, None, S, dist=dist, nu=nu or 0.0)) < RTOL
+    S[5] = -np.eye(d)
+    lp, info = cs.api.logpdf_percov(X, None, S, nu=nu)
+    assert info[5] == 1 and np.isnan(lp[5]) and np.isfinite(np.delete(lp, 5)).all()

@@ -209,3 +209,38 @@ def test_log_weight_resampler_restatement(oracle):
     a2 = oracle.metropolis_log(lw2, B, 7, step=3)
     moved = a2 != np.arange(N)
     assert not np.isinf(lw2[a2[moved]]).any()
+
+
+def _random_covariances(rng, N, d):
+    A = rng.standard_normal((N, d, d))
+    scale = np.exp(rng.uniform(-2, 2, size=(N, 1, 1)))
+    return scale * (A @ np.transpose(A, (0, 2, 1)) / d + np.eye(d))
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 8, 16])
+def test_per_particle_covariances_restatement(oracle, d):
+    """SURVEY.md 8(f) row 4.  The per-covariance density is the reference's pdf() with a
+    distribution object per particle (LU determinant + inverse per call, src/statistics.cc.cpp:
+    171-196, 295-324): checked against scipy; the batched Cholesky (the kernels' operation order)
+    against numpy."""
+    from scipy import stats
+    rng = np.random.default_rng(100 + d)
+    N = 40
+    S = _random_covariances(rng, N, d)
+    X = rng.standard_normal((N, d))
+    mu = rng.standard_normal((N, d))
+    L, logdet, info = oracle.chol_batched(S)
+    assert not info.any()
+    for i in range(N):
+        assert np.allclose(L[i], np.linalg.cholesky(S[i]), rtol=1e-13, atol=1e-14 * np.abs(L[i]).max())
+        assert np.isclose(logdet[i], np.linalg.slogdet(S[i])[1], rtol=1e-12, atol=1e-12)
+    p = oracle.pdf_percov(X, mu, S)
+    want = np.array([stats.multivariate_normal(mu[i], S[i]).pdf(X[i]) for i in range(N)])
+    assert np.allclose(p, want, rtol=1e-10)
+    pt = oracle.pdf_percov(X, mu[0], S, dist="mvt", nu=4.0)
+    want = np.array([stats.multivariate_t(mu[0], S[i], df=4.0).pdf(X[i]) for i in range(N)])
+    assert np.allclose(pt, want, rtol=1e-10)
+    # a covariance that is not positive definite is reported, with the index of the pivot
+    S[3] = np.eye(d)
+    S[3][d - 1, d - 1] = -1.0
+    assert oracle.chol_batched(S)[2][3] == d
