@@ -365,11 +365,13 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
           const int lo = kb;
           const int cnt = NB - lo;
           const int kbn = s == 3 ? kb + 1 : kb;  // the next step's k-block
-          const int lon = kbn;
+          [[maybe_unused]] const int lon = kbn;
+#ifndef EXP_NOLDSW  // (calibration builds: the factor fragments are read once per tile -- wrong results, attributes the LDS waits)
           if (kbn < NB) {
 #pragma unroll
             for (int cb = lon; cb < NB; ++cb) w_nxt[cb] = sF[(f + cnt + cb - lon) * 64 + lds_lane];
           }
+#endif
           double a = a_in[kb][s >> 1][s & 1];
           if (CENTRED && SHIFT) a -= sShift[16 * kb + pi_k(s, h)];
 #pragma unroll
