@@ -3,10 +3,15 @@ and the reference's published known answers.  Run on an MI355X with `pytest -m g
 
 Tolerances: log-densities 1e-6 relative (the north star's bar; observed ~1e-13 on these
 well-conditioned covariances), ancestor indices bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import DIMS, RESAMPLE_CASES, ROOT, spd
+
+# the dispatch-fuzz tests run this many seeds each (CUSMC_FUZZ_SEEDS=100 for a long soak)
+FUZZ_SEEDS = int(os.environ.get("CUSMC_FUZZ_SEEDS", "0"))
 
 pytestmark = pytest.mark.gpu
 
@@ -265,7 +270,7 @@ def test_padded_dimensions(cs, oracle, d, dist):
     D.close()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 6))
 def test_logpdf_random_shapes(cs, oracle, seed):
     """Dispatch fuzz: random d in [1, 256] (CUSMC_MAX_DIM), random N, row stride, base alignment, distribution and
     form (centred with mu, or reweight with F = I / general F), every output against the hoisted
@@ -540,7 +545,7 @@ def test_propagate_diagonal_models(cs, oracle, d, dist, nu):
     assert np.allclose(init.cpu().numpy(), want0, rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 4))
 def test_propagate_random_shapes(cs, oracle, seed):
     """Dispatch fuzz for the proposal draws: random d in [1, 256], dense or diagonal G and Q, MVN or
     Student-t, random shard, with and without ancestors, against the oracle's dense loops."""
