@@ -610,23 +610,31 @@ def test_filter_against_golden(cs, golden):
         assert np.allclose(out["weights"], golden["pf_%s_w" % dist], rtol=1e-6)
 
 
-def test_filter_against_oracle_larger(cs, oracle):
-    rng = np.random.default_rng(4)
-    d, T, N = 8, 6, 2000
+@pytest.mark.parametrize("d,dist,nu", [(8, "mvn", 0.0), (3, "mvt", 4.0), (16, "mvn", 0.0), (24, "mvt", 3.0),
+                                       (70, "mvn", 0.0), (130, "mvn", 0.0)])
+def test_filter_against_oracle_larger(cs, oracle, d, dist, nu):
+    """run() against the oracle's MCMC() loop with dense F, G, V, W, C0 on every kernel family the
+    time loop can take: the fused step (d <= 8), the three-launch step with the matrix-core proposal and
+    the QL-rotated reweight (16 <= d <= 128, on and off the 16-grid), and the row-wise proposal with
+    the wide log-pdf kernel (d > 128)."""
+    rng = np.random.default_rng(4 + d)
+    T, N = (6, 2000) if d <= 24 else (4, 600)
     Y = rng.standard_normal((T, d))
-    G = 0.9 * np.eye(d) + 0.05 * rng.standard_normal((d, d))
-    F = np.eye(d) + 0.05 * rng.standard_normal((d, d))
+    G = 0.9 * np.eye(d) + 0.05 * rng.standard_normal((d, d)) / np.sqrt(d / 8)
+    F = np.eye(d) + 0.05 * rng.standard_normal((d, d)) / np.sqrt(d / 8)
     V, W, C0 = spd(rng, d), 0.3 * spd(rng, d), spd(rng, d)
     m0 = rng.standard_normal(d)
-    out = cs.run(N, d, T, Y.T, m0, C0, F, G, V, W, 0.0, "metropolis", "mvn", seed=7, return_ancestors=True)
-    X, w, a = oracle.pf_run(Y, N, m0, C0, F, G, V, W, "mvn", 0.0, B=10, seed=7, hoisted=True)
-    # eigen square roots are unique only up to column order/sign; both sides use cyclic Jacobi in
-    # the same sweep order, so the factors coincide and trajectories can be compared directly
+    out = cs.run(N, d, T, Y.T, m0, C0, F, G, V, W, nu, "metropolis", dist, seed=7, return_ancestors=True)
+    X, w, a = oracle.pf_run(Y, N, m0, C0, F, G, V, W, dist, nu, B=10, seed=7, hoisted=True)
+    # eigen square roots are unique only up to column order/sign; both sides run the same
+    # Householder tridiagonalisation + implicit QL with the same ordering and sign convention, so
+    # the factors coincide and trajectories can be compared directly
     same = np.mean(out["ancestors"] == a)
-    assert same > 0.999
+    assert same > 0.995
     ok = (out["ancestors"] == a).all(axis=0)  # chains whose whole ancestry agrees
+    assert ok.mean() > 0.9
     assert np.allclose(out["posterior_x"][:, ok], X[:, ok], rtol=1e-8, atol=1e-8)
-    assert np.allclose(out["weights"][:, ok], w[:, ok], rtol=1e-6)
+    assert np.allclose(out["weights"][:, ok], w[:, ok], rtol=1e-6, atol=1e-300)
 
 
 @pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16])
