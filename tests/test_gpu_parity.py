@@ -858,3 +858,27 @@ def test_logpdf_per_particle_covariance(cs, oracle, d, dist):
     S[5] = -np.eye(d)
     lp, info = cs.api.logpdf_percov(X, None, S, nu=nu)
     assert info[5] == 1 and np.isnan(lp[5]) and np.isfinite(np.delete(lp, 5)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [16, 64, 100, 200])
+def test_far_centre_keeps_exact_subtraction(cs, oracle, d):
+    """The centre is subtracted from the particle BEFORE the factor is applied, as the reference's
+    r = y - F mu (src/statistics.cc.cpp:192): a distribution centred 1e12 standard deviations from
+    the origin is evaluated as accurately as one at the origin.  (Folding the centre into a bias,
+    z = W x - W c, would be free on the matrix cores -- the subtraction costs 3 - 6 % of a launch at
+    d = 64 -- but is wrong in the third digit here and gives up the bitwise shift identity
+    test_full_size_properties checks; measured and not adopted)"""
+    rng = np.random.default_rng(d)
+    sigma = spd(rng, d)
+    N = 500
+    for centre in (1e12, 30.0):
+        mu = centre * (1.0 + 0.1 * rng.random(d))
+        Xh = mu + rng.standard_normal((N, d))
+        D = cs.MultiVariateNormalDistribution(mu, sigma)
+        assert rel_err(D.pdf_batch(Xh), oracle.logpdf_hoisted(Xh, mu, sigma, None, "mvn", 0.0)) < RTOL
+        # reweight_G with F = I is the same form about y
+        Z = cs.MultiVariateNormalDistribution(None, sigma)
+        assert rel_err(Z.reweight(Xh, mu, np.eye(d)), oracle.logpdf_hoisted(mu[None, :] - Xh, None, sigma, None, "mvn", 0.0)) < RTOL
+        D.close()
+        Z.close()
