@@ -121,6 +121,12 @@ struct cusmc_ctx {
   DevBuf whi;        // high words of the weight vector (resampler, large N)
   DevBuf step_mats;  // [Q | G] of the fused filter step, re-uploaded only when they change
   std::vector<double> step_mats_host;
+  // proposal-draw parameter image (packed fragments / transposed factors / diagonals + m0) of the last
+  // draws() call and the host values it was built from: a filter calls with the same G and Q at every
+  // time step, and packing + uploading 2 d^2 doubles per step is what a small filter's step would cost
+  DevBuf draw_img;
+  std::vector<double> draw_key;
+  int draw_layout = 0;
 };
 
 struct cusmc_dist {
@@ -246,33 +252,35 @@ int ensure_M(cusmc_dist *dist)
   return CUSMC_OK;
 }
 
+// shift_dev / bias_dev: the plan's vectors, or (a time loop that uploaded every step's observation
+// vector in one table ahead of its launches) this step's rows of that table
 int run_logpdf(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx, int flags,
-               double *out_dev)
+               double *out_dev, const double *shift_dev = nullptr, const double *bias_dev = nullptr)
 {
   cusmc_ctx *ctx = dist->ctx;
   const Epilogue ep = make_epilogue(dist, flags);
   const int d = dist->d;
-  bool has_shift = false;
+  bool has_shift = shift_dev != nullptr;
   for (double v : dist->plan_shift) has_shift |= (v != 0.0);
+  const double *shift = shift_dev ? shift_dev : (const double *)dist->shift.p;
+  const double *bias = bias_dev ? bias_dev : (const double *)dist->bias.p;
   if (cusmc::mfma_wide_supported(d, X_dev, ldx)) {
     if (int rc = ensure_frags(dist, 2)) return rc;
     HIP_TRY(cusmc::launch_logpdf_mfma_wide(X_dev, N, ldx, d, dist->plan == 1, has_shift,
-                                           (const double *)dist->frags.p, (const double *)dist->shift.p,
-                                           (const double *)dist->bias.p, ep, out_dev, ctx->num_cus, ctx->stream));
+                                           (const double *)dist->frags.p, shift, bias, ep, out_dev, ctx->num_cus,
+                                           ctx->stream));
     return CUSMC_OK;
   }
   if (cusmc::mfma_supported(d, X_dev, ldx)) {
     if (int rc = ensure_frags(dist, 1)) return rc;
     HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan == 1, has_shift, (const double *)dist->frags.p,
-                                      (const double *)dist->shift.p, (const double *)dist->bias.p,
-                                      ep, out_dev, ctx->num_cus, ctx->stream));
+                                      shift, bias, ep, out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
   if (!cusmc::generic_supported(d))
     return fail(CUSMC_ERANGE, "d = %d is beyond the generic log-pdf kernel (and not a multiple of 16)", d);
   if (int rc = ensure_M(dist)) return rc;
-  HIP_TRY(cusmc::launch_logpdf_generic(X_dev, N, ldx, d, dist->plan_tri, (const double *)dist->Mdev.p,
-                                       (const double *)dist->shift.p, (const double *)dist->bias.p,
+  HIP_TRY(cusmc::launch_logpdf_generic(X_dev, N, ldx, d, dist->plan_tri, (const double *)dist->Mdev.p, shift, bias,
                                        ep, out_dev, ctx->num_cus, ctx->stream));
   return CUSMC_OK;
 }
@@ -378,6 +386,7 @@ CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &b : ctx->scratch) b.release();
+  ctx->draw_img.release();
   ctx->whi.release();
   ctx->step_mats.release();
   ctx->ring.release();
@@ -605,11 +614,6 @@ CUSMC_EXPORT int cusmc_metropolis_log_host(cusmc_ctx *ctx, const double *logw, u
 
 namespace {
 
-int upload_small(cusmc_ctx *ctx, DevBuf &buf, size_t offset_doubles, const double *src, size_t n)
-{
-  return ctx->ring.upload((double *)buf.p + offset_doubles, src, n * 8, ctx->stream);
-}
-
 int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const uint32_t *a_dev,
           const double *G, const double *Q, const double *m0, int d, double scale, uint64_t seed,
           uint32_t step, uint32_t domain, uint32_t first, uint32_t count, double *X_out_dev)
@@ -621,17 +625,39 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
   if (count == 0) return CUSMC_OK;
   if (!X_out_dev) return fail(CUSMC_EINVAL, "null output pointer");
   const size_t dd = (size_t)d * d;
+  // The device image of (Q, G, m0) in the layout the chosen kernel reads, built and uploaded only when
+  // the layout or the host values differ from the previous call's.
+  std::vector<double> key;
+  key.reserve(2 * dd + d + 2);
+  key.insert(key.end(), Q, Q + dd);
+  key.push_back(G ? 1.0 : 0.0);
+  if (G) key.insert(key.end(), G, G + dd);
+  key.push_back(m0 ? 1.0 : 0.0);
+  if (m0) key.insert(key.end(), m0, m0 + d);
+  auto image = [&](int layout, size_t doubles, auto &&build) -> int {
+    if (ctx->draw_layout == layout && ctx->draw_img.p && ctx->draw_key.size() == key.size() &&
+        !memcmp(ctx->draw_key.data(), key.data(), key.size() * 8))
+      return CUSMC_OK;
+    std::vector<double> img(doubles, 0.0);
+    build(img);
+    ctx->draw_layout = 0;
+    if (int rc = ctx->draw_img.reserve(doubles * 8)) return rc;
+    if (int rc = ctx->ring.upload(ctx->draw_img.p, img.data(), doubles * 8, ctx->stream)) return rc;
+    ctx->draw_layout = layout;
+    ctx->draw_key.swap(key);
+    return CUSMC_OK;
+  };
   if (cusmc::la::is_diagonal(Q, d) && (!G || cusmc::la::is_diagonal(G, d))) {
     // device image: [diag(Q) | diag(G) | m0]
-    std::vector<double> img(3 * (size_t)d, 0.0);
-    for (int j = 0; j < d; ++j) {
-      img[j] = Q[(size_t)j * d + j];
-      if (G) img[d + j] = G[(size_t)j * d + j];
-      if (m0) img[2 * d + j] = m0[j];
-    }
-    if (int rc = ctx->scratch[4].reserve(img.size() * 8)) return rc;
-    if (int rc = ctx->ring.upload(ctx->scratch[4].p, img.data(), img.size() * 8, ctx->stream)) return rc;
-    const double *base = (const double *)ctx->scratch[4].p;
+    if (int rc = image(1, 3 * (size_t)d, [&](std::vector<double> &img) {
+          for (int j = 0; j < d; ++j) {
+            img[j] = Q[(size_t)j * d + j];
+            if (G) img[d + j] = G[(size_t)j * d + j];
+            if (m0) img[2 * d + j] = m0[j];
+          }
+        }))
+      return rc;
+    const double *base = (const double *)ctx->draw_img.p;
     HIP_TRY(cusmc::launch_propagate_diag(kind, nu, X_prev_dev, a_dev, G ? base + d : nullptr, base,
                                          m0 ? base + 2 * d : nullptr, d, scale, seed, step, domain, first, count,
                                          X_out_dev, ctx->num_cus, ctx->stream));
@@ -642,19 +668,20 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
     // zero-padded to 16*ceil(d/16)
     const int nb = (d + 15) / 16, dp = 16 * nb;
     const size_t nf = (size_t)cusmc::mfma_num_frags(nb, false) * 64;
-    std::vector<double> img(2 * nf + d, 0.0), Mp;
-    auto pack = [&](const double *M, double *dst) {
-      if (dp == d) { cusmc::mfma_pack_frags(M, d, false, dst); return; }
-      Mp.assign((size_t)dp * dp, 0.0);
-      for (int i = 0; i < d; ++i) std::copy(M + (size_t)i * d, M + (size_t)(i + 1) * d, Mp.begin() + (size_t)i * dp);
-      cusmc::mfma_pack_frags(Mp.data(), dp, false, dst);
-    };
-    pack(Q, img.data());
-    if (G) pack(G, img.data() + nf);
-    if (m0) std::copy(m0, m0 + d, img.begin() + 2 * nf);
-    if (int rc = ctx->scratch[4].reserve(img.size() * 8)) return rc;
-    if (int rc = ctx->ring.upload(ctx->scratch[4].p, img.data(), img.size() * 8, ctx->stream)) return rc;
-    const double *base = (const double *)ctx->scratch[4].p;
+    if (int rc = image(2, 2 * nf + d, [&](std::vector<double> &img) {
+          std::vector<double> Mp;
+          auto pack = [&](const double *M, double *dst) {
+            if (dp == d) { cusmc::mfma_pack_frags(M, d, false, dst); return; }
+            Mp.assign((size_t)dp * dp, 0.0);
+            for (int i = 0; i < d; ++i) std::copy(M + (size_t)i * d, M + (size_t)(i + 1) * d, Mp.begin() + (size_t)i * dp);
+            cusmc::mfma_pack_frags(Mp.data(), dp, false, dst);
+          };
+          pack(Q, img.data());
+          if (G) pack(G, img.data() + nf);
+          if (m0) std::copy(m0, m0 + d, img.begin() + 2 * nf);
+        }))
+      return rc;
+    const double *base = (const double *)ctx->draw_img.p;
     HIP_TRY(cusmc::launch_propagate_mfma(kind, nu, X_prev_dev, a_dev, base, G ? base + nf : nullptr,
                                          m0 ? base + 2 * nf : nullptr, d, scale, seed, step, domain, first,
                                          count, X_out_dev, ctx->num_cus, ctx->stream));
@@ -662,27 +689,29 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
   }
   if (d > 128) {
     // device image: [Q^T | G^T | m0] (one workgroup per particle, kernels/propagate.hip)
-    std::vector<double> img(2 * dd + d, 0.0);
-    for (int i = 0; i < d; ++i)
-      for (int j = 0; j < d; ++j) {
-        img[(size_t)j * d + i] = Q[(size_t)i * d + j];
-        if (G) img[dd + (size_t)j * d + i] = G[(size_t)i * d + j];
-      }
-    if (m0) std::copy(m0, m0 + d, img.begin() + 2 * dd);
-    if (int rc = ctx->scratch[4].reserve(img.size() * 8)) return rc;
-    if (int rc = ctx->ring.upload(ctx->scratch[4].p, img.data(), img.size() * 8, ctx->stream)) return rc;
-    const double *base = (const double *)ctx->scratch[4].p;
+    if (int rc = image(3, 2 * dd + d, [&](std::vector<double> &img) {
+          for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+              img[(size_t)j * d + i] = Q[(size_t)i * d + j];
+              if (G) img[dd + (size_t)j * d + i] = G[(size_t)i * d + j];
+            }
+          if (m0) std::copy(m0, m0 + d, img.begin() + 2 * dd);
+        }))
+      return rc;
+    const double *base = (const double *)ctx->draw_img.p;
     HIP_TRY(cusmc::launch_propagate_rows(kind, nu, X_prev_dev, a_dev, G ? base + dd : nullptr, base,
                                          m0 ? base + 2 * dd : nullptr, d, scale, seed, step, domain, first, count,
                                          X_out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
   // device image: [Q | G | m0]
-  if (int rc = ctx->scratch[4].reserve((2 * dd + d) * 8)) return rc;
-  if (int rc = upload_small(ctx, ctx->scratch[4], 0, Q, dd)) return rc;
-  if (G) { if (int rc = upload_small(ctx, ctx->scratch[4], dd, G, dd)) return rc; }
-  if (m0) { if (int rc = upload_small(ctx, ctx->scratch[4], 2 * dd, m0, d)) return rc; }
-  const double *base = (const double *)ctx->scratch[4].p;
+  if (int rc = image(4, 2 * dd + d, [&](std::vector<double> &img) {
+        std::copy(Q, Q + dd, img.begin());
+        if (G) std::copy(G, G + dd, img.begin() + dd);
+        if (m0) std::copy(m0, m0 + d, img.begin() + 2 * dd);
+      }))
+    return rc;
+  const double *base = (const double *)ctx->draw_img.p;
   HIP_TRY(cusmc::launch_propagate(kind, nu, X_prev_dev, a_dev, G ? base + dd : nullptr, base,
                                   m0 ? base + 2 * dd : nullptr, d, scale, seed, step, domain, first,
                                   count, X_out_dev, ctx->num_cus, ctx->stream));
@@ -1052,43 +1081,52 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   rc = mark(0);
   if (rc) return cleanup(rc);
   // MCMC(): for t = 1..T-1: resample -> propagate -> reweight   src/mcmc.cpp:292-308
-  if (T > 1 && pf_step_is_fused(d, N)) {
-    // Small state: a time step is ONE launch, and for a small filter the per-step uploads of the
-    // observation (two 16..64-byte copies in the stream) would cost more than the launch.  All of Y is
-    // known here, so every step's shift (F = I: y_t) or bias (general F: W y_t) goes up in one
-    // table and the loop below is launches only.  Same values as the per-step plan, bit for bit.
-    rc = pf_step_prepare(obs, G, Qw.data(), Y + d, F);
+  if (T > 1) {
+    // All of Y is known here, so every step's observation vector -- the shift y_t (F = I) or the bias
+    // W y_t, rotated by Q^T when the general-F plan is (plan_affine) -- goes up in ONE table and the
+    // loop below is launches only: for a small filter the per-step uploads (two 16..2048-byte copies in
+    // the stream) would cost more than the launches.  Same values as the per-step plan, bit for bit.
+    const bool fused = pf_step_is_fused(d, N);
+    if (fused) rc = pf_step_prepare(obs, G, Qw.data(), Y + d, F);
+    else rc = plan_affine(obs, Y + d, F);
     if (rc) return cleanup(rc);
     const bool centred = obs->plan == 1;
-    ytab_host.assign((size_t)T * d, 0.0);
-    std::vector<double> b;
+    const size_t row = (size_t)((d + 63) / 64) * 64;  // the matrix-core kernels stage 16*NB entries
+    ytab_host.assign((size_t)T * row, 0.0);
+    std::vector<double> b, rb;
     for (uint32_t t = 1; t < T; ++t) {
       const double *y = Y + (size_t)t * d;
+      double *dst = ytab_host.data() + (size_t)t * row;
       if (centred) {
-        std::copy(y, y + d, ytab_host.begin() + (size_t)t * d);
+        std::copy(y, y + d, dst);
       } else {
         cusmc::la::matvec(obs->W.data(), y, d, b);
-        std::copy(b.begin(), b.end(), ytab_host.begin() + (size_t)t * d);
+        if (!obs->plan_Qt.empty()) {
+          cusmc::la::matvec(obs->plan_Qt.data(), b.data(), d, rb);
+          b.swap(rb);
+        }
+        std::copy(b.begin(), b.end(), dst);
       }
     }
-    rc = ytab.reserve((size_t)T * d * 8);
+    rc = ytab.reserve((size_t)T * row * 8);
     if (rc) return cleanup(rc);
-    if (hipMemcpyAsync(ytab.p, ytab_host.data(), (size_t)T * d * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    if (hipMemcpyAsync(ytab.p, ytab_host.data(), (size_t)T * row * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
       return cleanup(fail(CUSMC_EHIP, "observation table upload failed"));
     const double *tab = (const double *)ytab.p;
     for (uint32_t t = 1; t < T; ++t) {
-      rc = pf_step_launch(obs, kind, df, w + (size_t)(t - 1) * N, X + (size_t)(t - 1) * slice, N, B, scale, seed, t,
-                          0, N, a + (size_t)t * N, X + (size_t)t * slice, w + (size_t)t * N, CUSMC_OUT_DENSITY,
-                          centred ? tab + (size_t)t * d : (const double *)obs->shift.p,
-                          centred ? (const double *)obs->bias.p : tab + (size_t)t * d);
-      if (!rc) rc = mark(t);
-      if (rc) return cleanup(rc);
-    }
-  } else {
-    for (uint32_t t = 1; t < T; ++t) {
-      rc = cusmc_pf_step_dev(obs, kind, df, w + (size_t)(t - 1) * N, X + (size_t)(t - 1) * slice, N, G, Qw.data(),
-                             Y + (size_t)t * d, F, B, scale, seed, t, 0, N, a + (size_t)t * N,
-                             X + (size_t)t * slice, w + (size_t)t * N, CUSMC_OUT_DENSITY);
+      const double *w_prev = w + (size_t)(t - 1) * N, *X_prev = X + (size_t)(t - 1) * slice;
+      uint32_t *a_t = a + (size_t)t * N;
+      double *X_t = X + (size_t)t * slice, *w_t = w + (size_t)t * N;
+      const double *shift_t = centred ? tab + (size_t)t * row : (const double *)obs->shift.p;
+      const double *bias_t = centred ? (const double *)obs->bias.p : tab + (size_t)t * row;
+      if (fused) {
+        rc = pf_step_launch(obs, kind, df, w_prev, X_prev, N, B, scale, seed, t, 0, N, a_t, X_t, w_t,
+                            CUSMC_OUT_DENSITY, shift_t, bias_t);
+      } else {
+        rc = cusmc_metropolis_dev(ctx, w_prev, N, B, seed, t, 0, N, a_t);
+        if (!rc) rc = draws(ctx, kind, df, X_prev, a_t, G, Qw.data(), nullptr, d, scale, seed, t, 2u, 0, N, X_t);
+        if (!rc) rc = run_logpdf(obs, X_t, N, d, CUSMC_OUT_DENSITY, w_t, shift_t, bias_t);
+      }
       if (!rc) rc = mark(t);
       if (rc) return cleanup(rc);
     }
