@@ -76,6 +76,9 @@ bool propagate_mfma_supported(int d, const void *X_prev, const void *X_out)
 //      1: propagate, one launch      x = [diag(c)] Q xi + G x_prev[a]
 //      2: first half of two          x = [diag(c)] Q xi
 //      3: second half                x += G x_prev[a]
+//      4: diagonal G, one launch     x = [diag(c)] Q xi + g .* x_prev[a]   (fragsG = the d diagonal entries:
+//         a random-walk or AR(1)-per-component state with correlated noise needs no second product; the
+//         ancestor's row is gathered straight into the C layout, 8 bytes per lane per output register)
 // PAD: d is not 16*NB (factors zero-padded on the host) or rows are not 16-byte aligned: the last
 // k-block of the gathered row is loaded element by element, column clamped into the row, columns
 // >= d zeroed; normals for pairs past d are not drawn; outputs past d are not stored.
@@ -88,18 +91,19 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
 {
   constexpr int D = 16 * NB;
   constexpr int NFRAG = 4 * NB * NB;
-  constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0;
+  constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0, DIAG_G = MODE == 4;
   constexpr bool SPLIT_ACC = (MVT && HAS_Q && HAS_G) || HAS_M0 || MODE == 3;  // accG separate from accQ
   extern __shared__ double lds[];
   double *sQ = lds;                                  // NFRAG x 64 (HAS_Q)
-  double *sG = sQ + (HAS_Q ? NFRAG * 64 : 0);        // NFRAG x 64 (HAS_G) or m0 padded to D (HAS_M0)
-  int *sNext = reinterpret_cast<int *>(sG + (HAS_G ? NFRAG * 64 : (HAS_M0 ? D : 0)));
+  double *sG = sQ + (HAS_Q ? NFRAG * 64 : 0);        // NFRAG x 64 (HAS_G), or m0 / diag(G) padded to D
+  int *sNext = reinterpret_cast<int *>(sG + (HAS_G ? NFRAG * 64 : (HAS_M0 || DIAG_G ? D : 0)));
 
   for (int i = threadIdx.x; i < NFRAG * 32; i += 512) {
     if (HAS_Q) reinterpret_cast<v2d *>(sQ)[i] = reinterpret_cast<const v2d *>(fragsQ)[i];
     if (HAS_G) reinterpret_cast<v2d *>(sG)[i] = reinterpret_cast<const v2d *>(fragsG)[i];
   }
   if (HAS_M0 && threadIdx.x < D) sG[threadIdx.x] = (int)threadIdx.x < d ? m0[threadIdx.x] : 0.0;
+  if (DIAG_G && threadIdx.x < D) sG[threadIdx.x] = (int)threadIdx.x < d ? fragsG[threadIdx.x] : 0.0;
   if (threadIdx.x == 0) *sNext = 0;
   __syncthreads();
 
@@ -140,6 +144,16 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
           xg[NB - 1][s >> 1][s & 1] = col < rem ? v : 0.0;
         }
       }
+    }
+    // diagonal G: the ancestor's values in the C layout (output dim 16 cb + h + 4 r), issued before the RNG
+    double xc[DIAG_G ? NB : 1][4];
+    if constexpr (DIAG_G) {
+      const uint32_t anc = a ? a[live ? local : (long)count - 1] : gi;
+      const double *row = X_prev + (long)anc * d + h;
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xc[cb][r] = (!PAD || 16 * cb + h + 4 * r < d) ? row[16 * cb + 4 * r] : 0.0;
     }
     // normals in operand order: xi[kb][s] = xi_p[16 kb + pi(s, h)]
     double xi[NB][4];
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
           double v = HAS_Q ? accQ[cb][r] : dst[16 * cb + 4 * r];
           if (MVT && HAS_Q) v *= sqrt((double)nu / pm_chi_square(gi, (uint32_t)j, step, k0, k1, nu));
           if (SPLIT_ACC) v += accG[cb][r];
+          if (DIAG_G) v += fma(sG[j], xc[cb][r], 0.0);  // (the one non-zero term of the dense kernels' sum)
           dst[16 * cb + 4 * r] = v;
         }
       }
@@ -208,8 +223,8 @@ static hipError_t launch_pm(float nu, const double *X_prev, const uint32_t *a, c
                             int num_cus, hipStream_t stream)
 {
   constexpr int NFRAG = 4 * NB * NB;
-  constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0;
-  const size_t lds_bytes = (size_t)((HAS_Q ? NFRAG * 64 : 0) + (HAS_G ? NFRAG * 64 : (HAS_M0 ? 16 * NB : 0)) + 2) * sizeof(double);
+  constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0, DIAG_G = MODE == 4;
+  const size_t lds_bytes = (size_t)((HAS_Q ? NFRAG * 64 : 0) + (HAS_G ? NFRAG * 64 : (HAS_M0 || DIAG_G ? 16 * NB : 0)) + 2) * sizeof(double);
   auto kern = propagate_mfma_kernel<NB, MVT, MODE, PAD>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -225,25 +240,26 @@ static hipError_t launch_pm(float nu, const double *X_prev, const uint32_t *a, c
 }
 
 // fragsQ / fragsG: mfma_pack_frags of the factors zero-padded to 16*ceil(d/16) (fragsG == NULL: the
-// initial draw, + m0).
+// initial draw, + m0).  g_is_diagonal: fragsG holds the d diagonal entries of G instead.
 hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const uint32_t *a,
-                                 const double *fragsQ, const double *fragsG, const double *m0, int d,
+                                 const double *fragsQ, const double *fragsG, bool g_is_diagonal, const double *m0, int d,
                                  double scale, uint64_t seed, uint32_t step, uint32_t domain,
                                  uint32_t first, uint32_t count, double *X_out, int num_cus,
                                  hipStream_t stream)
 {
   if (count == 0) return hipSuccess;
   const bool mvt = kind == CUSMC_MVT, gather = fragsG != nullptr;
-  const bool pad = d % 16 != 0 || (gather && (uintptr_t)X_prev % 16 != 0);
+  const bool pad = d % 16 != 0 || (gather && !g_is_diagonal && (uintptr_t)X_prev % 16 != 0);
 #define CUSMC_ARGS nu, X_prev, a, fragsQ, fragsG, m0, d, scale, seed, step, domain, first, count, X_out, num_cus, stream
 #define CUSMC_PMV(nb, mode)                                                                                  \
   (mvt ? (pad ? launch_pm<nb, true, mode, true>(CUSMC_ARGS) : launch_pm<nb, true, mode, false>(CUSMC_ARGS))  \
        : (pad ? launch_pm<nb, false, mode, true>(CUSMC_ARGS) : launch_pm<nb, false, mode, false>(CUSMC_ARGS)))
 #define CUSMC_PM1(nb) /* both factors fit the LDS */ \
-  case nb: return gather ? CUSMC_PMV(nb, 1) : CUSMC_PMV(nb, 0);
+  case nb: return !gather ? CUSMC_PMV(nb, 0) : g_is_diagonal ? CUSMC_PMV(nb, 4) : CUSMC_PMV(nb, 1);
 #define CUSMC_PM2(nb) /* one factor per launch */                                   \
   case nb: {                                                                        \
     if (!gather) return CUSMC_PMV(nb, 0);                                           \
+    if (g_is_diagonal) return CUSMC_PMV(nb, 4);                                     \
     const hipError_t e = CUSMC_PMV(nb, 2);                                          \
     return e != hipSuccess ? e : CUSMC_PMV(nb, 3);                                  \
   }

@@ -75,11 +75,12 @@ hipError_t launch_propagate(int kind, float nu, const double *X_prev, const uint
                             hipStream_t stream);
 
 // --- kernels/propagate_mfma.hip : d = 16*NB <= 64 ------------------------------------------------
-// fragsQ / fragsG: dense mfma_pack_frags images of Q and G (fragsG == nullptr: initial draw, + m0)
+// fragsQ / fragsG: dense mfma_pack_frags images of Q and G (fragsG == nullptr: initial draw, + m0);
+// g_is_diagonal: fragsG is the d-vector diag(G) instead (no second product)
 bool propagate_mfma_supported(int d, const void *X_prev, const void *X_out);
 hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const uint32_t *a,
-                                 const double *fragsQ, const double *fragsG, const double *m0, int d,
-                                 double scale, uint64_t seed, uint32_t step, uint32_t domain,
+                                 const double *fragsQ, const double *fragsG, bool g_is_diagonal, const double *m0,
+                                 int d, double scale, uint64_t seed, uint32_t step, uint32_t domain,
                                  uint32_t first, uint32_t count, double *X_out, int num_cus,
                                  hipStream_t stream);
 
