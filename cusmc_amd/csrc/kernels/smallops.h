@@ -10,6 +10,22 @@
 
 namespace cusmc {
 
+// A polynomial coefficient as a SCALAR operand.  Left alone, hipcc evaluates Horner steps as
+// v_fmac_f64 (dst += a * b), which needs the coefficient copied into dst first -- one v_mov_b64 of
+// VALU issue per step, ~30 per Box-Muller pair.  An f64 literal cannot be an inline operand, but an
+// SGPR pair can: through this no-op the coefficient lives in SGPRs and each step is one v_fma_f64.
+// Same operations on the same values: results are unchanged bit for bit.
+#ifndef CUSMC_NO_SCALAR_COEFFS
+static __device__ __forceinline__ double sc(double c)
+{
+  asm volatile("" : "+s"(c));  // (volatile: materialised at the point of use -- hoisted out of the loops, two dozen
+                                  // coefficients exceed the SGPR file and come back through v_readlane)
+  return c;
+}
+#else
+static __device__ __forceinline__ double sc(double c) { return c; }
+#endif
+
 // ln(x) for finite x > 0, < 1 ulp: the classic reduction x = 2^e m, m in [sqrt(1/2), sqrt(2)),
 // ln(m) = 2 atanh(s), s = (m - 1) / (m + 1), with the degree-7 minimax polynomial in s^2 and the
 // hi/lo split of ln 2 of Sun's fdlibm e_log.c (constants from there).  The library log (ocml) costs
@@ -58,9 +74,9 @@ static __device__ __forceinline__ void sincos_2pi(double u, double &c, double &s
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   const double v = z * x;
-  const double ps = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
-  const double sx = fma(v, fma(z, ps, S1), x);
-  const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+  const double ps = fma(z, fma(z, fma(z, fma(z, sc(S6), sc(S5)), sc(S4)), sc(S3)), sc(S2));
+  const double sx = fma(v, fma(z, ps, sc(S1)), x);
+  const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, sc(C6), sc(C5)), sc(C4)), sc(C3)), sc(C2)), sc(C1));
   const double hz = 0.5 * z;
   const double w1 = 1.0 - hz;
   const double cx = w1 + (((1.0 - w1) - hz) + z * pc);
@@ -87,7 +103,7 @@ static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, do
 
 // chi^2_nu = 2 Gamma(nu/2, 1) by Marsaglia-Tsang (the reference's device sampler,
 // src/mvt_dist.cu.cpp:20-61); counter layout as oracle/cusmc_oracle.c:chi_square_for.
-static __device__ double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, uint32_t k0,
+static __device__ __attribute__((noinline)) double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, uint32_t k0,
                                         uint32_t k1, float nu)
 {
   double a = 0.5 * (double)nu;
