@@ -40,9 +40,8 @@ static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, int d, cons
                             double *out, int num_cus, hipStream_t stream)
 {
   constexpr int NFRAG = 4 * NB * (NB + 1) / 2;  // lower triangular in both forms
-  constexpr bool WREG = mfma_factor_in_regs<NB>();
   constexpr int THREADS = mfma_threads<NB>();
-  const size_t lds_bytes = (size_t)(32 * NB + 4 + (WREG ? 0 : NFRAG * 64)) * sizeof(double);
+  const size_t lds_bytes = (size_t)(32 * NB + 4 + NFRAG * 64) * sizeof(double);  // (the factor passes through LDS in every variant)
   const long num_tiles = (N + 15) / 16;
   auto kern = logpdf_mfma_kernel<NB, CENTRED, SHIFT, 0, EPI, PAD>;
   if (lds_bytes > 64 * 1024) {

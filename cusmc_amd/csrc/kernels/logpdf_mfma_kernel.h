@@ -131,9 +131,10 @@ __device__ __forceinline__ double finish_epi(double q, const Epilogue &ep)
 //     A tail worth having would have to live in a loop of its own, and then pays a pipeline
 //     drain per wave at the hand-over: not pursued.
 //
-// Factor residency.  WREG (triangular, d <= 64): each lane keeps its 2*NB*(NB+1) factor values in
-// registers for the whole kernel (80 VGPRs at d = 64) -- the tile loop then has no LDS reads at
-// all.  Otherwise the factor is staged once per workgroup in LDS and read one k-step ahead.
+// Factor residency.  The factor is staged once per workgroup in LDS.  WREG (d <= 64): each lane
+// then copies its 2*NB*(NB+1) factor values into registers for the whole kernel (80 VGPRs at
+// d = 64) -- the tile loop has no LDS reads at all.  Otherwise the fragments stay in LDS and are
+// read one k-step ahead.
 //
 // Things that were tried on the prologue and the loop shape and measured SLOWER (ablate.hip quick
 // mode, same box): touching the first tiles' cache lines before the factor loads (+2.3 us: 64
@@ -203,11 +204,15 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   // (a relaxed workgroup-scope atomic, not `volatile`: volatile LDS accesses make the memory
   // legaliser drain vmcnt as well, which costs the tile loop its counted waits)
   unsigned *sNext = reinterpret_cast<unsigned *>(sBias + 16 * NB);
-  double *sF = sBias + 16 * NB + 4;  // NFRAG x 64 (only when !WREG)
+  double *sF = sBias + 16 * NB + 4;  // NFRAG x 64 (WREG: the prologue's broadcast buffer only)
 
-  if (!WREG) {
-    // Stage the factor: all of a chunk's 16-byte loads are issued before the first LDS write,
-    // so the prologue costs one memory round trip per chunk, not one per element.
+  {
+    // Stage the factor in LDS: all of a chunk's 16-byte loads are issued before the first LDS write,
+    // so the prologue costs one memory round trip per chunk, not one per element.  The register-
+    // resident variants (WREG) go through LDS as well and pick their fragments up after the barrier:
+    // the factor then crosses L2 -> CU once per workgroup instead of once per wave (8 x 20 KB at
+    // d = 64, 41 MB chip-wide in the first microseconds of every launch): -0.9 us per launch,
+    // 94.1 -> 93.2 us median over three interleaved runs (scripts/calib/ablate.hip).
     constexpr int NV = NFRAG * 32;  // 16-byte elements
     constexpr int SC = 8;
     const v2d *g = reinterpret_cast<const v2d *>(frags);
@@ -292,12 +297,12 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     }
   };
 
+  __syncthreads();
   double wreg[WREG ? NFRAG : 1];
   if (WREG) {
 #pragma unroll
-    for (int f = 0; f < NFRAG; ++f) wreg[f] = frags[f * 64 + lane];
+    for (int f = 0; f < NFRAG; ++f) wreg[f] = sF[f * 64 + lane];
   }
-  __syncthreads();
   // the shift values a lane subtracts are the same for every tile: 4*NB registers instead of
   // 4*NB LDS reads per tile (d <= 64; above that the registers are spoken for)
   double shreg[(CENTRED && SHIFT && WREG) ? NB : 1][4];

@@ -18,7 +18,7 @@
 
 using namespace cusmc;
 static constexpr int KT = mfma_threads<4>();  // launch shape of the kernel under test
-static constexpr size_t KLDS = (size_t)(32 * 4 + 4 + (mfma_factor_in_regs<4>() ? 0 : 40 * 64)) * 8;
+static constexpr size_t KLDS = (size_t)(32 * 4 + 4 + 40 * 64) * 8;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
