@@ -145,7 +145,10 @@ __device__ __forceinline__ double finish_epi(double q, const Epilogue &ep)
 // fixed slot pinned a workgroup to the same HBM channels (no effect: 94.4-95.2 us for rotations 0,
 // 1, 8, 37, 97 on one box); giving every wave its first round by birth and an LDS-only barrier, so
 // that the factor loads and the first tile's loads are in flight together (+0.6 us: 96.0 -> 96.6
-// median over three interleaved runs, although the load-free variant gains 1 us).
+// median over three interleaved runs, although the load-free variant gains 1 us) -- and again after
+// the factor started going through LDS, this time with the first tile's loads really in flight
+// across the barrier (s_waitcnt vmcnt(8) before the LDS writes, lgkmcnt(0) only before s_barrier):
+// 95.4 -> 95.2 us, inside the noise, not kept.
 template <int NB>
 __host__ __device__ constexpr int mfma_threads()
 {
