@@ -329,6 +329,22 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   // as in-loop ds_read_b64.
   int lds_lane = lane;
 
+  // Student-t epilogue, batched (EPI == 2 unless EXP_NOBATCH): after the 4-lane reduction every lane
+  // (p, h) holds particle p's q, so the q of four consecutive tiles are parked in the four h-groups
+  // (one per-lane select each) and the log1p epilogue runs once per four tiles on all 64 lanes --
+  // its ~40 f64 VALU instructions are serialised with the MFMAs, a quarter as often.
+#ifdef EXP_NOBATCH
+  constexpr bool BATCH = false;
+#else
+  constexpr bool BATCH = EPI == 2;
+#endif
+  double q_parked = 0.0;
+  long row_parked = N;  // N = nothing parked
+  unsigned parked = 0;  // tiles computed by this wave (wave-uniform)
+  auto flush = [&]() {
+    if (row_parked < N) out[row_parked] = finish_epi<EPI>(q_parked, ep);
+    row_parked = N;
+  };
   auto compute_tile = [&](unsigned tu, const v2d(&a_in)[NB][2]) {
     const long t = tu;
     v4d acc[NB];
@@ -407,8 +423,17 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
       q += __shfl_xor(q, 16);
       q += __shfl_xor(q, 32);
     }
-    // lanes 0..15: particles 0..15 of the tile, one 128-byte line
-    if (lane < (t == last ? (int)tail_rows : 16)) out[t * 16 + lane] = finish_epi<EPI>(q, ep);
+    if constexpr (BATCH) {
+      const int slot = (int)(parked & 3u);
+      ++parked;
+      const bool mine = h == slot;
+      q_parked = mine ? q : q_parked;
+      row_parked = mine ? t * 16 + p : row_parked;  // (rows >= N of the last tile park as "nothing": flush() checks)
+      if (slot == 3) flush();
+    } else {
+      // lanes 0..15: particles 0..15 of the tile, one 128-byte line
+      if (lane < (t == last ? (int)tail_rows : 16)) out[t * 16 + lane] = finish_epi<EPI>(q, ep);
+    }
   };
 
   // ABL == 4 (diagnostic build only): shader-clock and 100 MHz wall stamps per wave, written past
@@ -456,6 +481,7 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
       }
     }
   }
+  if constexpr (BATCH) flush();
   if (STAMP && lane == 0) {
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out + num_tiles * 16);
     const long wid = (long)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
