@@ -15,6 +15,8 @@
 // in smallops.h (shared with the fused filter step).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "smallops.h"
 
 namespace cusmc {
@@ -74,7 +76,11 @@ __global__ __launch_bounds__(256) void hiword_kernel(const double *__restrict__ 
 }
 
 // The truncated-table chain pays off once the doubles no longer fit one XCD's L2 (4 MB).
-bool metropolis_wants_hiwords(uint32_t N) { return (uint64_t)N * 8 > (3u << 20); }
+bool metropolis_wants_hiwords(uint32_t N)
+{
+  if (const char *e = getenv("CUSMC_MH_HI")) return e[0] == '1';  // (switch: for A/B timing)
+  return (uint64_t)N * 8 > (3u << 20);
+}
 
 hipError_t launch_hiwords(const double *w, uint32_t N, uint32_t *whi, int num_cus, hipStream_t stream)
 {
