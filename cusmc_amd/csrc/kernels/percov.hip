@@ -8,7 +8,7 @@
 //     logpdf_percov_kernel      out_i = log p(x_i; mu_i, Sigma_i), MVN or Student-t
 //
 // One lane = one matrix, d a template parameter so that every loop unrolls.  The lower triangle
-// lives in registers up to d = 8 (36 doubles) and above that in LDS as [element][lane]
+// lives in registers up to d = 8 (36 doubles) and above that in LDS as [element][lane (+1 pad)]
 // (consecutive lanes on consecutive banks: conflict-free; d = 16 needs 136 doubles per lane,
 // which no register file holds); it is factored in place column by column, and for the density
 // the forward substitution z = L^-1 (x - mu) follows in registers.  Every sum is an fma chain in
@@ -24,7 +24,10 @@ namespace cusmc {
 
 namespace {
 
-constexpr int kPercovLanes = 64;  // one wave per workgroup: an LDS slab is [element][64]
+constexpr int kPercovLanes = 64;   // one wave per workgroup
+constexpr int kSlabStride = 65;    // an LDS slab is [element][64 lanes + 1]: a lane's own accesses are conflict-free
+                                   // (consecutive lanes, consecutive words) and so, nearly, are the transposed ones
+                                   // of the cooperative store below
 
 constexpr int tri_index(int r, int c) { return r * (r + 1) / 2 + c; }
 template <int D>
@@ -36,10 +39,10 @@ template <int D, bool REG>
 struct Triangle {
   double reg[REG ? D * (D + 1) / 2 : 1];
   double *lds;
-  __device__ __forceinline__ double get(int e) const { return REG ? reg[e] : lds[e * kPercovLanes]; }
+  __device__ __forceinline__ double get(int e) const { return REG ? reg[e] : lds[e * kSlabStride]; }
   __device__ __forceinline__ void set(int e, double v)
   {
-    if (REG) reg[e] = v; else lds[e * kPercovLanes] = v;
+    if (REG) reg[e] = v; else lds[e * kSlabStride] = v;
   }
 };
 
@@ -83,25 +86,54 @@ __device__ __forceinline__ int cholesky_lane(const double *__restrict__ S, Trian
 
 }  // namespace
 
+// The factors leave through LDS: a wave's 64 matrices are contiguous in L (64 D^2 doubles), so instead
+// of each lane storing its own rows 8 bytes at a time (64 distinct lines per instruction) the wave
+// stores the block as D^2 fully coalesced 512-byte instructions.  Register variant: staged as
+// [lane][D^2 + 1]; LDS variant: read back transposed from the slab itself.
 template <int D>
 __global__ __launch_bounds__(kPercovLanes) void cholesky_batched_kernel(
     const double *__restrict__ S, long N, double *__restrict__ L, double *__restrict__ logdet,
     int *__restrict__ info)
 {
   constexpr bool REG = percov_in_regs<D>();
+  constexpr int DD = D * D;
   extern __shared__ double slab[];
   Triangle<D, REG> a;
   a.lds = slab + threadIdx.x;
-  for (long i = (long)blockIdx.x * kPercovLanes + threadIdx.x; i < N; i += (long)gridDim.x * kPercovLanes) {
-    double ld;
-    const int bad = cholesky_lane<D, REG>(S + i * (D * D), a, &ld);
-    double *Li = L + i * (D * D);
+  const int lane = threadIdx.x;
+  for (long i0 = (long)blockIdx.x * kPercovLanes; i0 < N; i0 += (long)gridDim.x * kPercovLanes) {
+    const long i = i0 + lane;
+    double ld = 0.0;
+    int bad = 0;
+    if (i < N) bad = cholesky_lane<D, REG>(S + i * DD, a, &ld);
+    if constexpr (REG) {
+      double *mine = slab + lane * (DD + 1);
 #pragma unroll
-    for (int r = 0; r < D; ++r)
+      for (int r = 0; r < D; ++r)
 #pragma unroll
-      for (int c = 0; c < D; ++c) Li[r * D + c] = c <= r ? a.get(tri_index(r, c)) : 0.0;
-    if (logdet) logdet[i] = ld;
-    if (info) info[i] = bad;
+        for (int c = 0; c < D; ++c) mine[r * D + c] = c <= r ? a.get(tri_index(r, c)) : 0.0;
+    }
+    __syncthreads();  // (one wave: orders the LDS writes before the transposed reads)
+    const long total = (N - i0 < kPercovLanes ? N - i0 : (long)kPercovLanes) * DD;
+    double *dst = L + i0 * DD;
+#pragma unroll 4
+    for (int c = 0; c < DD; ++c) {
+      const int flat = c * kPercovLanes + lane;
+      const int m = flat / DD, e = flat - m * DD;
+      double v;
+      if constexpr (REG) {
+        v = slab[m * (DD + 1) + e];
+      } else {
+        const int r = e / D, col = e - r * D;
+        v = col <= r ? slab[tri_index(r, col) * kSlabStride + m] : 0.0;
+      }
+      if (flat < total) dst[flat] = v;
+    }
+    __syncthreads();  // the slab is rewritten by the next batch
+    if (i < N) {
+      if (logdet) logdet[i] = ld;
+      if (info) info[i] = bad;
+    }
   }
 }
 
@@ -148,16 +180,17 @@ static long percov_blocks(int64_t N, int num_cus)
 }
 
 template <int D>
-static size_t percov_lds_bytes()
+static size_t percov_lds_bytes(bool factor_out)
 {
-  return percov_in_regs<D>() ? 0 : (size_t)(D * (D + 1) / 2) * kPercovLanes * sizeof(double);
+  if (percov_in_regs<D>()) return factor_out ? (size_t)kPercovLanes * (D * D + 1) * sizeof(double) : 0;  // the store's staging buffer
+  return (size_t)(D * (D + 1) / 2) * kSlabStride * sizeof(double);
 }
 
 template <int D>
 static hipError_t launch_chol(const double *S, int64_t N, double *L, double *logdet, int *info, int num_cus,
                               hipStream_t stream)
 {
-  const size_t lds = percov_lds_bytes<D>();
+  const size_t lds = percov_lds_bytes<D>(true);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cholesky_batched_kernel<D>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -172,7 +205,7 @@ template <int D>
 static hipError_t launch_lp(const double *X, int64_t N, int64_t ldx, const double *mu, int64_t ldmu, const double *S,
                             const Epilogue &ep, double *out, int *info, int num_cus, hipStream_t stream)
 {
-  const size_t lds = percov_lds_bytes<D>();
+  const size_t lds = percov_lds_bytes<D>(false);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(logpdf_percov_kernel<D>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
