@@ -44,11 +44,8 @@ static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, int d, cons
   const size_t lds_bytes = (size_t)(32 * NB + 4 + NFRAG * 64) * sizeof(double);  // (the factor passes through LDS in every variant)
   const long num_tiles = (N + 15) / 16;
   auto kern = logpdf_mfma_kernel<NB, CENTRED, SHIFT, 0, EPI, PAD>;
-  if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-  }
+  static std::atomic<unsigned long long> lds_configured{0};
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
   // one persistent workgroup per CU (its waves share the round counter), fewer when there is
   // less work than that
   long blocks = num_cus;

@@ -277,11 +277,8 @@ static hipError_t launch_t(int kind, float nu, const double *X_prev, const uint3
 {
   const size_t lds_bytes = (size_t)2 * T * (d | 1) * sizeof(double);
   auto kern = propagate_kernel<T>;
-  if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-  }
+  static std::atomic<unsigned long long> lds_configured{0};
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
   const long num_tiles = ((long)count + T - 1) / T;
   int per_cu = (int)((160 * 1024) / lds_bytes);
   const int max_per_cu = 2048 / T > 8 ? 8 : 2048 / T;

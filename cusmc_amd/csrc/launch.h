@@ -2,9 +2,28 @@
 // Internal to libcusmc_hip.so; the public surface is include/cusmc_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 namespace cusmc {
+
+// Raises a kernel's dynamic-LDS limit above the default 64 KB, once per (kernel instantiation, device):
+// `done` is the instantiation's own bit mask of devices already configured (a context may live on any
+// device of the process, and the attribute is per device).
+inline hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<unsigned long long> &done)
+{
+  if (bytes <= 64 * 1024) return hipSuccess;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
+  if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+  return e;
+}
+
 
 // Epilogue of the quadratic form q = |z|^2:
 //   mvn: lognorm - q/2                              (src/statistics.cc.cpp:179, as a log)
