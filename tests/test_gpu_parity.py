@@ -673,6 +673,35 @@ def test_filter_against_oracle_larger(cs, oracle, d, dist, nu):
     assert np.allclose(out["weights"][:, ok], w[:, ok], rtol=1e-6, atol=1e-300)
 
 
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 4))
+def test_filter_random_models(cs, oracle, seed):
+    """Dispatch fuzz for run(): random d in [1, 140], Normal or Student-t, F = I or general, G and W
+    diagonal or dense -- whatever kernels the time loop picks (fused step, observation table rows as
+    shift or as rotated bias, diagonal / one-product / two-product proposals, row-wise above d = 128), the
+    trajectories are the oracle's MCMC() loop's."""
+    rng = np.random.default_rng(5000 + seed)
+    for case in range(3):
+        d = int(rng.choice([rng.integers(1, 9), rng.integers(9, 65), rng.integers(65, 141)]))
+        dist = str(rng.choice(["mvn", "mvt"]))
+        nu = float(rng.choice([3.0, 4.0, 7.5])) if dist == "mvt" else 0.0
+        T = int(rng.integers(2, 6))
+        N = int(rng.integers(200, 1200)) if d <= 64 else int(rng.integers(100, 400))
+        general_F, dense_G, dense_W = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        F = np.eye(d) + (0.05 * rng.standard_normal((d, d)) / np.sqrt(max(d, 8) / 8) if general_F else 0.0)
+        G = np.diag(0.7 + 0.3 * rng.random(d)) + (0.05 * rng.standard_normal((d, d)) / np.sqrt(max(d, 8) / 8) if dense_G else 0.0)
+        W = 0.3 * spd(rng, d) if dense_W else np.diag(0.1 + 0.3 * rng.random(d))
+        V, C0 = spd(rng, d), spd(rng, d)
+        m0 = rng.standard_normal(d)
+        Y = rng.standard_normal((T, d))
+        tag = (seed, case, d, dist, nu, T, N, general_F, dense_G, dense_W)
+        out = cs.run(N, d, T, Y.T, m0, C0, F, G, V, W, nu, "metropolis", dist, seed=11 + case, return_ancestors=True)
+        X, w, a = oracle.pf_run(Y, N, m0, C0, F, G, V, W, dist, nu, B=10, seed=11 + case, hoisted=True)
+        ok = (out["ancestors"] == a).all(axis=0)  # chains whose whole ancestry agrees
+        assert ok.mean() > 0.9, tag
+        assert np.allclose(out["posterior_x"][:, ok], X[:, ok], rtol=1e-8, atol=1e-8), tag
+        assert np.allclose(out["weights"][:, ok], w[:, ok], rtol=1e-6, atol=1e-300), tag
+
+
 @pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0)])
 @pytest.mark.parametrize("general_F,diag_model", [(False, False), (True, False), (False, True)])
