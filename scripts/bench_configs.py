@@ -125,7 +125,7 @@ def main():
     for name, N, d, T in (("C3 run() N=1e6 d=2 T=100", 1_000_000, 2, 100), ("run() N=2e5 d=64 T=10", 200_000, 64, 10)):
         I = np.eye(d)
         Y = np.cumsum(0.03 * np.random.default_rng(0).standard_normal((d, T)), axis=1)
-        cusmc_amd.run(N, d, T, Y, np.zeros(d), I, I, I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn", seed=3)  # (first call loads the code objects)
+        cusmc_amd.run(N, d, T, Y, np.zeros(d), I, I, I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn", seed=3)  # (first call: HIP initialisation, code objects)
         t0 = time.perf_counter()
         res = cusmc_amd.run(N, d, T, Y, np.zeros(d), I, I, I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn", seed=3)
         t = time.perf_counter() - t0  # (the result stays alive: releasing 2.4 GB of pages costs 0.1 s by itself)
