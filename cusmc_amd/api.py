@@ -18,8 +18,11 @@ Conventions carried over from R: matrices arrive as numpy arrays indexed [row, c
 `Y` is d x T with columns = time (src/run.rcpp.cpp:91); a batched `x` is d x N with columns =
 particles.  Densities (not logs) are returned wherever the reference returns densities.
 """
+import atexit
+import collections
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -47,6 +50,10 @@ class Context:
 
     def __init__(self, device=-1):
         self._h = C.c_void_p()
+        # distribution handles point into their context (device buffers, stream): closing the context
+        # closes them first, so that teardown order -- e.g. of module globals at interpreter exit --
+        # cannot leave a handle pointing at a destroyed context
+        self._distributions = weakref.WeakSet()
         check(_lib.lib().cusmc_ctx_create(device, C.byref(self._h)))
 
     def set_stream(self, stream_ptr):
@@ -68,6 +75,8 @@ class Context:
 
     def close(self):
         if self._h:
+            for dist in list(self._distributions):
+                dist.close()
             _lib.lib().cusmc_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -167,6 +176,7 @@ class _Distribution:
         self._h = C.c_void_p()
         check(_lib.lib().cusmc_dist_create(self.ctx._h, self._kind, _ptr(self.mu), _ptr(self.sigma),
                                            self.d, C.c_float(self.nu), C.byref(self._h)))
+        self.ctx._distributions.add(self)
 
     # -- scalar interface, as the reference's virtuals ---------------------------------------
     def pdf(self, y, F=None):
@@ -400,23 +410,49 @@ def _batched_density(dist, x, d):
     raise ValueError("x must be a length-d vector or a d x N matrix")
 
 
+# The R-level density calls build a distribution object per call (as the reference does:
+# src/mvn_dist.rcpp.cpp:55).  A loop over particles with the same (mu, sigma) -- the reference's typical
+# R usage -- would pay a factorisation, four device allocations and their release per particle, so the
+# last few objects are kept: a repeated call is an upload of x, one launch and 8 bytes back.
+_DIST_CACHE_SIZE = 4
+_dist_cache = collections.OrderedDict()
+
+
+def _cached_distribution(cls, mu, sigma, *nu):
+    mu, sigma = _f64(mu), _f64(sigma)
+    key = (cls.__name__, tuple(np.float32(v).tobytes() for v in nu), mu.tobytes(), sigma.shape, sigma.tobytes())
+    dist = _dist_cache.get(key)
+    if dist is not None:
+        _dist_cache.move_to_end(key)
+        return dist
+    dist = cls(mu, sigma, *nu)
+    _dist_cache[key] = dist
+    while len(_dist_cache) > _DIST_CACHE_SIZE:
+        _dist_cache.popitem(last=False)[1].close()
+    return dist
+
+
+def _clear_dist_cache():
+    while _dist_cache:
+        _dist_cache.popitem()[1].close()
+
+
+# distribution handles point into their context: at interpreter exit they must go first, whatever
+# order the module globals are torn down in
+atexit.register(_clear_dist_cache)
+
+
 def MVNPDF(x, mu, sigma):
     """double MVNPDF(x, mu, sigma) -- src/mvn_dist.rcpp.cpp:52-58: F = I; MVN(mu,sigma).pdf(x, F).
     Returns the DENSITY.  Batched extension: a d x N matrix x returns N densities."""
-    dist = MultiVariateNormalDistribution(mu, sigma)
-    try:
-        return _batched_density(dist, x, dist.d)
-    finally:
-        dist.close()
+    dist = _cached_distribution(MultiVariateNormalDistribution, mu, sigma)
+    return _batched_density(dist, x, dist.d)
 
 
 def MVTPDF(x, mu, sigma, nu):
     """double MVTPDF(x, mu, sigma, nu) -- src/mvt_dist.rcpp.cpp:60-66."""
-    dist = MultiVariateTStudentDistribution(mu, sigma, nu)
-    try:
-        return _batched_density(dist, x, dist.d)
-    finally:
-        dist.close()
+    dist = _cached_distribution(MultiVariateTStudentDistribution, mu, sigma, nu)
+    return _batched_density(dist, x, dist.d)
 
 
 def MVN(mu, sigma, compat=False):

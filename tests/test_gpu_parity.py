@@ -947,3 +947,17 @@ def test_far_centre_keeps_exact_subtraction(cs, oracle, d):
         assert rel_err(Z.reweight(Xh, mu, np.eye(d)), oracle.logpdf_hoisted(mu[None, :] - Xh, None, sigma, None, "mvn", 0.0)) < RTOL
         D.close()
         Z.close()
+
+
+@pytest.mark.gpu
+def test_interpreter_exit_with_live_handles(cs):
+    """A process that ends with distribution handles still alive -- normally, or through an uncaught
+    exception -- exits cleanly: the context closes its distributions first whatever order the module
+    globals are torn down in (a handle outliving its context used to abort the interpreter at exit)."""
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "scripts", "exit_check.py")
+    ok = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    exc = subprocess.run([sys.executable, script, "x"], capture_output=True, text=True, timeout=300)
+    assert exc.returncode == 1 and "RuntimeError" in exc.stderr and "terminate called" not in exc.stderr, exc.stderr[-2000:]
