@@ -112,6 +112,8 @@ struct StagingRing {
 
 }  // namespace
 
+struct cusmc_dist;
+
 struct cusmc_ctx {
   int device = 0;
   int num_cus = 0;
@@ -127,6 +129,10 @@ struct cusmc_ctx {
   DevBuf draw_img;
   std::vector<double> draw_key;
   int draw_layout = 0;
+  // the distributions created on this context: destroying the context orphans them (their device
+  // buffers go, their handles stay destroyable), because callers' finalizers -- R's at session end,
+  // Python's at interpreter exit -- run in no particular order
+  std::vector<cusmc_dist *> dists;
 };
 
 struct cusmc_dist {
@@ -154,7 +160,7 @@ using cusmc::Epilogue;
 
 int activate(cusmc_ctx *ctx)
 {
-  if (!ctx) return fail(CUSMC_EINVAL, "null context");
+  if (!ctx) return fail(CUSMC_EINVAL, "null context (or the context this handle was created on has been destroyed)");
   HIP_TRY(hipSetDevice(ctx->device));
   return CUSMC_OK;
 }
@@ -385,6 +391,14 @@ CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
   if (!ctx) return CUSMC_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (cusmc_dist *dist : ctx->dists) {
+    dist->frags.release();
+    dist->Mdev.release();
+    dist->shift.release();
+    dist->bias.release();
+    dist->ctx = nullptr;
+  }
+  ctx->dists.clear();
   for (auto &b : ctx->scratch) b.release();
   ctx->draw_img.release();
   ctx->whi.release();
@@ -456,6 +470,7 @@ CUSMC_EXPORT int cusmc_dist_create(cusmc_ctx *ctx, int kind, const double *mu, c
     dist->lognorm = std::lgamma(0.5 * (double)nu_plus_d) - std::lgamma(0.5 * (double)nu) -
                     0.5 * (double)d * std::log(pi * (double)nu) - 0.5 * logdet;
   }
+  ctx->dists.push_back(dist);
   *out = dist;
   return CUSMC_OK;
 }
@@ -463,12 +478,15 @@ CUSMC_EXPORT int cusmc_dist_create(cusmc_ctx *ctx, int kind, const double *mu, c
 CUSMC_EXPORT int cusmc_dist_destroy(cusmc_dist *dist)
 {
   if (!dist) return CUSMC_OK;
-  (void)hipSetDevice(dist->ctx->device);
-  (void)hipStreamSynchronize(dist->ctx->stream);
-  dist->frags.release();
-  dist->Mdev.release();
-  dist->shift.release();
-  dist->bias.release();
+  if (cusmc_ctx *ctx = dist->ctx) {  // (null: the context went first and took the device buffers with it)
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    dist->frags.release();
+    dist->Mdev.release();
+    dist->shift.release();
+    dist->bias.release();
+    ctx->dists.erase(std::remove(ctx->dists.begin(), ctx->dists.end(), dist), ctx->dists.end());
+  }
   delete dist;
   return CUSMC_OK;
 }

@@ -23,6 +23,9 @@
  *   - Work is enqueued on the context's HIP stream; `_dev` calls return without waiting
  *     (use cusmc_ctx_synchronize), `_host` calls return when the output buffer is filled.
  *   - One context per host thread (thread-compatible, not thread-safe) -- all R needs.
+ *   - Destroying a context orphans the distributions created on it (their device buffers go with
+ *     it): a later call through such a handle returns CUSMC_EINVAL, and cusmc_dist_destroy still
+ *     accepts it -- finalizers (R's at session end, Python's at interpreter exit) run in any order.
  *   - RNG: counter-based Philox4x32-10, key = seed, counter = (index, sub, step, domain); the
  *     full contract is in DESIGN.md section "RNG contract" and restated in oracle/cusmc_oracle.c.
  */

@@ -961,3 +961,21 @@ def test_interpreter_exit_with_live_handles(cs):
     assert ok.returncode == 0, ok.stderr[-2000:]
     exc = subprocess.run([sys.executable, script, "x"], capture_output=True, text=True, timeout=300)
     assert exc.returncode == 1 and "RuntimeError" in exc.stderr and "terminate called" not in exc.stderr, exc.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_context_destroyed_before_its_distribution(cs):
+    """C-ABI lifetime rule: destroying a context orphans the distributions created on it -- their
+    device buffers go with it, a later call through such a handle fails with a status instead of
+    touching freed memory, and the handle can still be destroyed (finalizers run in any order)."""
+    ctx = cs.Context()
+    D = cs.MultiVariateNormalDistribution(np.zeros(20), np.eye(20), ctx=ctx)
+    assert np.isfinite(D.pdf_batch(np.zeros((3, 20)))).all()
+    ctx._distributions.discard(D)  # bypass the Python-level ordering: exercise the library's own
+    ctx.close()
+    with pytest.raises(cs.CusmcError, match="destroyed"):
+        D.pdf_batch(np.zeros((3, 20)))
+    D.close()
+    E = cs.MultiVariateNormalDistribution(np.zeros(20), np.eye(20))  # the default context is unaffected
+    assert np.isfinite(E.pdf_batch(np.zeros((3, 20)))).all()
+    E.close()
