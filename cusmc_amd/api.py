@@ -455,25 +455,34 @@ def MVTPDF(x, mu, sigma, nu):
     return _batched_density(dist, x, dist.d)
 
 
+_eigen_cache = collections.OrderedDict()  # sigma -> Q, for repeated R-level draws from one covariance
+
+
+def _cached_eigen_sqrt(sigma):
+    key = (sigma.shape, sigma.tobytes())
+    Q = _eigen_cache.get(key)
+    if Q is None:
+        Q = _eigen_cache[key] = eigenSolver(sigma)
+        while len(_eigen_cache) > _DIST_CACHE_SIZE:
+            _eigen_cache.popitem(last=False)
+    else:
+        _eigen_cache.move_to_end(key)
+    return Q
+
+
 def MVN(mu, sigma, compat=False):
     """VectorXd MVN(mu, sigma) -- src/mvn_dist.rcpp.cpp:31-37.  The reference passes `sigma`
     ITSELF as the square-root factor Q (:35) and inflates the variance 3x (F6); compat=True
     reproduces that distribution, the default draws from N(mu, sigma)."""
-    dist = MultiVariateNormalDistribution(mu, sigma)
-    try:
-        Q = dist.sigma if compat else eigenSolver(dist.sigma)
-        return dist.sample(Q, 200, compat=compat)[0]
-    finally:
-        dist.close()
+    dist = _cached_distribution(MultiVariateNormalDistribution, mu, sigma)
+    Q = dist.sigma if compat else _cached_eigen_sqrt(dist.sigma)
+    return dist.sample(Q, 200, compat=compat)[0]
 
 
 def MVT(mu, sigma, nu, compat=False):
     """VectorXd MVT(mu, sigma, nu) -- src/mvt_dist.rcpp.cpp:28-49 (Q = eigen square root)."""
-    dist = MultiVariateTStudentDistribution(mu, sigma, nu)
-    try:
-        return dist.sample(eigenSolver(dist.sigma), 200, compat=compat)[0]
-    finally:
-        dist.close()
+    dist = _cached_distribution(MultiVariateTStudentDistribution, mu, sigma, nu)
+    return dist.sample(_cached_eigen_sqrt(dist.sigma), 200, compat=compat)[0]
 
 
 def metropolis_hastings(w, N, B):
