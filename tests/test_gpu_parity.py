@@ -257,7 +257,7 @@ def test_padded_dimensions(cs, oracle, d, dist):
     assert np.isfinite(got[:N][good]).all()
     want = oracle.logpdf_hoisted(Xh[good], mu, sigma, None, dist, 4.0)
     assert rel_err(got[:N][good], want) < RTOL
-    # reweight_G with a general F (dense affine plan, padded likewise)
+    # reweight_G with a general F (QL-rotated affine plan, padded likewise)
     F = np.eye(d) + 0.05 * rng.standard_normal((d, d))
     y = rng.standard_normal(d)
     Xg = torch.from_numpy(Xh[good][:3000]).cuda().contiguous()
