@@ -8,8 +8,8 @@
 // register file nor LDS, and one wave cannot hold 16 output blocks of accumulators for several
 // particle tiles.  So the OUTPUT dimension is split over the waves of a workgroup:
 //   * one workgroup per CU; it walks groups of GP particles (32, or 64 at d = 128);
-//   * wave w owns the PAIR of output blocks (q, NB-1-q), q = w % (NB/2), for two particle tiles
-//     (the tiles 2r, 2r+1 of the group, r = w / (NB/2)).  In the triangular form block cb needs
+//   * a wave owns the PAIR of output blocks (q, NB-1-q) for the group's two particle tiles (NB = 12:
+//     the last two pairs are shared by two waves each, one tile per wave -- see wide_waves()).  In the triangular form block cb needs
 //     k-blocks 0..cb, so every pair costs (q+1) + (NB-q) = NB+1 block-products: all waves carry
 //     exactly the same number of MFMAs (136 / 8 = 17 at d = 256);
 //   * accumulators are 2 tiles x 2 blocks x 8 = 32 VGPRs, which leaves the register file free
@@ -46,9 +46,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 __host__ __device__ constexpr int wide_pairs(int nb) { return nb / 2; }
-__host__ __device__ constexpr int wide_row_halves(int nb) { return nb == 8 ? 2 : 1; }
-__host__ __device__ constexpr int wide_waves(int nb) { return wide_pairs(nb) * wide_row_halves(nb); }
-__host__ __device__ constexpr int wide_gp(int nb) { return 32 * wide_row_halves(nb); }  // particles per group
+// EIGHT compute waves (two per SIMD) for both block counts.  A unit of work is (output pair, particle
+// tile of the group's two).  NB = 16: 8 pairs, wave w owns pair w and both tiles.  NB = 12: 6 pairs = 12
+// units: waves 0..3 own pairs 0..3 with both tiles, waves 4..7 own one tile each of pairs 4 and 5 -- every
+// SIMD (waves w and w + 4) then carries three units; six waves with two units each would leave two SIMDs
+// with four units and two with two (the first NB = 12 mapping: 48.8 TFLOP/s at d = 192).
+__host__ __device__ constexpr int wide_waves(int nb) { return (void)nb, 8; }
+__host__ __device__ constexpr int wide_gp(int nb) { return (void)nb, 32; }  // particles per group
 __host__ __device__ constexpr int wide_pi(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
 
 // Block count the kernel runs d with: 12 up to d = 192, 16 up to d = 256.  (d = 128 belongs to the
@@ -79,7 +83,7 @@ static long wide_stream_frags(int nb, int q)
 static size_t wide_lds_bytes(int nb)
 {
   const int tiles = wide_gp(nb) / 16;
-  return (size_t)(2 * nb * 4 * tiles * 64 + 2 * wide_waves(nb) * 32 + 32 * nb) * sizeof(double);
+  return (size_t)(2 * nb * 4 * tiles * 64 + 2 * wide_pairs(nb) * 32 + 32 * nb) * sizeof(double);
 }
 
 size_t mfma_wide_frag_doubles(int nb)
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
   constexpr int XBUF = NB * 4 * TILES * 64;  // doubles per staging buffer
   extern __shared__ double lds[];
   double *sX = lds;                  // [2][NB][2 halves][TILES][64 lanes][2]
-  double *sPartial = sX + 2 * XBUF;  // [2][WAVES][32]
-  double *sShift = sPartial + 2 * WAVES * 32;
+  double *sPartial = sX + 2 * XBUF;  // [2][P pairs][32 particles]
+  double *sShift = sPartial + 2 * P * 32;
   double *sBias = sShift + 16 * NB;
 
   for (int i = threadIdx.x; i < 16 * NB; i += THREADS) {
@@ -199,7 +203,10 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 
   // ---------------- compute waves ---------------------------------------------------------------
   const int p = lane & 15, h = lane >> 4;
-  const int q = w % P, rhalf = w / P;  // scalar: output pair, row half
+  // scalar: this wave's output pair q, its first tile and how many tiles it carries
+  const bool split = NB == 12 && w >= 4;
+  const int q = split ? 4 + ((w - 4) >> 1) : w;
+  const int tile0 = split ? (w - 4) & 1 : 0;
   const int lo = q, hi = NB - 1 - q;
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(frags), 0, (int)frag_bytes, 0x00020000);
   const int wbyte0 = streams.byte_off[q];
@@ -218,13 +225,15 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
     for (int i = 0; i < 2; ++i) w0[s][i] = load_w(s * 2 + i);
 
   __syncthreads();  // the first group is staged
+  auto run = [&](auto tpw_tag) {
+  constexpr int TPW = decltype(tpw_tag)::value;  // tiles per wave: 2, or 1 for the split pairs of NB = 12
   int parity = 0;
   for (long g = blockIdx.x; g < num_groups; g += G, parity ^= 1) {
     // this wave's two tiles of the current buffer: slab (kb, h2, t) holds, per lane, the operands
     // of k-steps 2 h2 and 2 h2 + 1
-    const v2d *xw = reinterpret_cast<const v2d *>(sX + parity * XBUF) + (rhalf * 2) * 64 + lane;
+    const v2d *xw = reinterpret_cast<const v2d *>(sX + parity * XBUF) + tile0 * 64 + lane;
 
-    v4d acc[2][2];  // [tile][member: 0 = lo block, 1 = hi block]
+    v4d acc[TPW][2];  // [tile][member: 0 = lo block, 1 = hi block]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       v4d init = v4d{0.0, 0.0, 0.0, 0.0};
@@ -232,8 +241,8 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
         const double *b = sBias + 16 * (m ? hi : lo) + h;
         init = v4d{b[0], b[4], b[8], b[12]};
       }
-      acc[0][m] = init;
-      acc[1][m] = init;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t][m] = init;
     }
 
     // Lookahead.  A k-block is only 8 (two live blocks) or 4 (one) MFMAs per wave, 520 / 260
@@ -241,14 +250,14 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
     // current / next k-block (L2, ~600+ cycles), xa/xb its particle operands (LDS, ~150).  The
     // k loop is unrolled by two so that the sets swap roles without copies.
     double wc[4][2], wn[4][2];
-    v2d xa[2][2], xb[2][2];  // [half][tile]
+    v2d xa[2][TPW], xb[2][TPW];  // [half][tile]
     int f = 0;  // fragment cursor in this wave's stream (scalar)
-    auto load_x = [&](int kb, v2d(&x)[2][2]) {
+    auto load_x = [&](int kb, v2d(&x)[2][TPW]) {
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
         const v2d *src = xw + ((kb * 2 + h2) * TILES) * 64;
-        x[h2][0] = src[0];
-        x[h2][1] = src[64];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) x[h2][t] = src[t * 64];
       }
     };
 #pragma unroll
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
     // one k-block with M live members (slot i = member 2 - M + i): prefetch the next k-block's
     // operands into (wnext, xnext), then 4 k-steps of 2*M MFMAs from (wcur, xcur)
     auto kblock = [&](auto mtag, int kb, int mn, double(&wcur)[4][2], double(&wnext)[4][2],
-                      v2d(&xcur)[2][2], v2d(&xnext)[2][2]) {
+                      v2d(&xcur)[2][TPW], v2d(&xnext)[2][TPW]) {
       constexpr int M = decltype(mtag)::value;
       constexpr int C0 = 2 - M;
       f += 4 * M;
@@ -273,27 +282,29 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
       load_x(kb + 1, xnext);  // one k-block past the end stays inside LDS and is never used
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        double r0 = xcur[s >> 1][0][s & 1], r1 = xcur[s >> 1][1][s & 1];
+        double r[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) r[t] = xcur[s >> 1][t][s & 1];
         if constexpr (PAD) {
           // columns >= d of the padded k-blocks hold the next row's leading values (or zeros past
           // the end of X): not this particle's, possibly not finite -- they must not reach the
           // matrix cores even against a zero factor column
           if (kb >= d_true / 16) {  // uniform
             const bool keepc = 16 * kb + wide_pi(s, h) < d_true;
-            r0 = keepc ? r0 : 0.0;
-            r1 = keepc ? r1 : 0.0;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) r[t] = keepc ? r[t] : 0.0;
           }
         }
         if (CENTRED && SHIFT) {
           const double sh = sShift[16 * kb + wide_pi(s, h)];
-          r0 -= sh;
-          r1 -= sh;
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) r[t] -= sh;
         }
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-          acc[0][C0 + i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wcur[s][i], r0, acc[0][C0 + i], 0, 0, 0);
-          acc[1][C0 + i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wcur[s][i], r1, acc[1][C0 + i], 0, 0, 0);
-        }
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            acc[t][C0 + i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wcur[s][i], r[t], acc[t][C0 + i], 0, 0, 0);
       }
     };
     // a phase = k-blocks [kb_lo, kb_hi) with M live members; `odd` tells which register set is
@@ -326,9 +337,9 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
       run_phase(std::integral_constant<int, 1>{}, lo + 1, hi + 1, odd);
     }
 
-    // partial sums of squares over this wave's two output blocks, per particle
+    // partial sums of squares over this wave's two output blocks, per particle: slot [pair][tile][p]
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TPW; ++t) {
       double qq = 0.0;
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -336,18 +347,21 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
         for (int r = 0; r < 4; ++r) qq = fma(acc[t][m][r], acc[t][m][r], qq);
       qq += __shfl_xor(qq, 16);
       qq += __shfl_xor(qq, 32);
-      if (h == 0) sPartial[(parity * WAVES + w) * 32 + t * 16 + p] = qq;
+      if (h == 0) sPartial[(parity * P + q) * 32 + (tile0 + t) * 16 + p] = qq;
     }
     __syncthreads();  // partials visible; the loader has completed the other buffer
-    if (q == 0 && lane < 32) {  // fixed summation order -> bitwise reproducible
-      const double *sp = sPartial + (parity * WAVES + rhalf * P) * 32 + lane;
+    if (w == 0 && lane < 32) {  // fixed summation order over the pairs -> bitwise reproducible
+      const double *sp = sPartial + parity * P * 32 + lane;
       double tot = sp[0];
 #pragma unroll
       for (int k = 1; k < P; ++k) tot += sp[k * 32];
-      const long row = g * GP + rhalf * 32 + lane;
+      const long row = g * GP + lane;
       if (row < N) out[row] = finish_wide(tot, ep);
     }
   }
+  };
+  if (split) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 2>{});
 }
 
 template <int NB>
