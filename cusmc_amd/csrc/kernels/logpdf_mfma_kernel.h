@@ -173,6 +173,8 @@ __host__ __device__ constexpr int mfma_sets()  // operand register sets in rotat
 {
 #ifdef EXP_SETS
   return NB <= 4 ? EXP_SETS : 2;
+#elif defined(EXP_SETS_BIG)  // calibration: a third operand set for the LDS-factor variants too
+  return NB <= EXP_SETS_BIG ? 3 : 2;
 #else
   // Two sets (one tile in flight behind the one being multiplied) beat three at every d <= 64
   // without a shift: 91.2 vs 94.6 us at d = 64, 93.2 vs 95.1 at d = 32 (interleaved runs on one
