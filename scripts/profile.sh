@@ -17,5 +17,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" --no-pmc --no-cpu --steps 5 --warmup 2 > "$OUT/write.log" 2>&1
 # (4) the other BASELINE configs' kernels (resampler, wide kernel, fused filter step, proposal draws)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/configs" -- python3 "$R/scripts/bench_configs.py" > "$OUT/configs.log" 2>&1
+# (5), (6) matrix-core utilisation and LDS bank conflicts of every MFMA kernel
+rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d "$OUT/mfma" -- python3 "$R/scripts/mfma_util_probe.py" > "$OUT/mfma.log" 2>&1
+rocprofv3 --pmc LdsBankConflict --kernel-trace --output-format csv -d "$OUT/lds" -- python3 "$R/scripts/mfma_util_probe.py" > "$OUT/lds.log" 2>&1
+python3 "$R/scripts/summarize_pmc.py" "$OUT/mfma" MfmaUtil > "$OUT/pmc_mfma_util.md"
+python3 "$R/scripts/summarize_pmc.py" "$OUT/lds" LdsBankConflict > "$OUT/pmc_lds_conflicts.md"
 python3 "$R/scripts/summarize_profile.py" "$OUT" > "$OUT/summary.md"
 cat "$OUT/summary.md"
