@@ -9,7 +9,7 @@
 // particle tiles.  So the OUTPUT dimension is split over the waves of a workgroup:
 //   * one workgroup per CU; it walks groups of GP particles (32, or 64 at d = 128);
 //   * a wave owns the PAIR of output blocks (q, NB-1-q) for the group's two particle tiles (NB = 12:
-//     the last two pairs are shared by two waves each, one tile per wave -- see wide_waves()).  In the triangular form block cb needs
+//     four pairs and four single blocks -- see wide_waves()).  In the triangular form block cb needs
 //     k-blocks 0..cb, so every pair costs (q+1) + (NB-q) = NB+1 block-products: all waves carry
 //     exactly the same number of MFMAs (136 / 8 = 17 at d = 256);
 //   * accumulators are 2 tiles x 2 blocks x 8 = 32 VGPRs, which leaves the register file free
@@ -46,13 +46,21 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 __host__ __device__ constexpr int wide_pairs(int nb) { return nb / 2; }
-// EIGHT compute waves (two per SIMD) for both block counts.  A unit of work is (output pair, particle
-// tile of the group's two).  NB = 16: 8 pairs, wave w owns pair w and both tiles.  NB = 12: 6 pairs = 12
-// units: waves 0..3 own pairs 0..3 with both tiles, waves 4..7 own one tile each of pairs 4 and 5 -- every
-// SIMD (waves w and w + 4) then carries three units; six waves with two units each would leave two SIMDs
-// with four units and two with two (the first NB = 12 mapping: 48.8 TFLOP/s at d = 192).
+// EIGHT compute waves (two per SIMD: waves w and w + 4) for both block counts, each carrying its output
+// blocks for BOTH particle tiles of a group (every fragment it loads feeds two MFMAs).
+//   NB = 16: wave w owns the pair (w, 15 - w): 17 block-products per tile, the same for every wave.
+//   NB = 12: six pairs do not spread over four SIMDs (two SIMDs with four pair-tiles, two with two: the
+//   first mapping, 48.8 TFLOP/s at d = 192).  Waves 0..3 own the pairs (w, 11 - w) (13 block-products),
+//   waves 4..7 a single block each -- 7, 4, 6, 5 (8, 5, 7, 6 block-products): the SIMDs carry 21, 18, 20
+//   and 19 block-products per tile where 19.5 would be perfect.
 __host__ __device__ constexpr int wide_waves(int nb) { return (void)nb, 8; }
 __host__ __device__ constexpr int wide_gp(int nb) { return (void)nb, 32; }  // particles per group
+// output blocks of wave w: (lo, hi), lo = -1 for a wave with a single block
+__host__ __device__ constexpr int wide_lo(int nb, int w) { return nb == 12 && w >= 4 ? -1 : w; }
+__host__ __device__ constexpr int wide_hi(int nb, int w)
+{
+  return nb == 12 && w >= 4 ? (w == 4 ? 7 : w == 5 ? 4 : w == 6 ? 6 : 5) : nb - 1 - w;
+}
 __host__ __device__ constexpr int wide_pi(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
 
 // Block count the kernel runs d with: 12 up to d = 192, 16 up to d = 256.  (d = 128 belongs to the
@@ -74,22 +82,23 @@ static bool wide_needs_pad(int d, const void *X, int64_t ldx)
   return d != 16 * mfma_wide_nb(d) || (uintptr_t)X % 16 != 0 || ldx % 2 != 0;
 }
 
-// fragments in the stream of pair q (kernel loop order: kb, s, live members)
-static long wide_stream_frags(int nb, int q)
+// fragments in the stream of wave w (kernel loop order: kb, s, live members)
+static long wide_stream_frags(int nb, int w)
 {
-  return 4L * (2 * (q + 1) + (nb - 1 - 2 * q));  // both up to kb = q, then the high block alone
+  const int lo = wide_lo(nb, w), hi = wide_hi(nb, w);
+  return lo < 0 ? 4L * (hi + 1) : 4L * (2 * (lo + 1) + (hi - lo));  // both up to kb = lo, then the high block alone
 }
 
 static size_t wide_lds_bytes(int nb)
 {
   const int tiles = wide_gp(nb) / 16;
-  return (size_t)(2 * nb * 4 * tiles * 64 + 2 * wide_pairs(nb) * 32 + 32 * nb) * sizeof(double);
+  return (size_t)(2 * nb * 4 * tiles * 64 + 2 * wide_waves(nb) * 32 + 32 * nb) * sizeof(double);
 }
 
 size_t mfma_wide_frag_doubles(int nb)
 {
   size_t n = 0;
-  for (int q = 0; q < wide_pairs(nb); ++q) n += (size_t)wide_stream_frags(nb, q) * 64;
+  for (int w = 0; w < wide_waves(nb); ++w) n += (size_t)wide_stream_frags(nb, w) * 64;
   return n + 9 * 64;  // zero tail: the kernel prefetches one k-block past a stream's end
 }
 
@@ -100,13 +109,13 @@ void mfma_wide_pack_frags(const double *M, int d, double *frags)
   const size_t total = mfma_wide_frag_doubles(nb);
   for (size_t i = total - 9 * 64; i < total; ++i) frags[i] = 0.0;
   size_t f = 0;
-  for (int q = 0; q < wide_pairs(nb); ++q) {
-    const int lo = q, hi = nb - 1 - q;
+  for (int w = 0; w < wide_waves(nb); ++w) {
+    const int lo = wide_lo(nb, w), hi = wide_hi(nb, w);
     for (int kb = 0; kb < nb; ++kb)
       for (int s = 0; s < 4; ++s)
         for (int m = 0; m < 2; ++m) {
           const int cb = m ? hi : lo;
-          if (cb < kb) continue;  // (lower triangular)
+          if (cb < kb) continue;  // (lower triangular; also skips the absent member lo = -1)
           for (int l = 0; l < 64; ++l) {
             const int j = l & 15, h = l >> 4;
             frags[f * 64 + l] = M[(size_t)(16 * cb + j) * d + 16 * kb + wide_pi(s, h)];
@@ -123,7 +132,7 @@ static __device__ __forceinline__ double finish_wide(double q, const Epilogue &e
   return ep.out_density ? exp(lp) : lp;
 }
 
-struct WideStreams { int byte_off[8]; };  // start of each pair's fragment stream
+struct WideStreams { int byte_off[8]; };  // start of each wave's fragment stream
 
 // ABL (scripts/calib only; 0 in the library): 1 = fragments not re-fetched, 2 = next group's rows
 // not fetched, 3 = neither.  Attribution of stall time; results are wrong by construction.
@@ -134,7 +143,6 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
     const double *__restrict__ bias, Epilogue ep, double *__restrict__ out, long num_groups,
     int d_true = 16 * NB)
 {
-  constexpr int P = wide_pairs(NB);
   constexpr int WAVES = wide_waves(NB);  // compute waves; wave WAVES is the loader
   constexpr int THREADS = 64 * (WAVES + 1);
   constexpr int GP = wide_gp(NB);
@@ -142,8 +150,8 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
   constexpr int XBUF = NB * 4 * TILES * 64;  // doubles per staging buffer
   extern __shared__ double lds[];
   double *sX = lds;                  // [2][NB][2 halves][TILES][64 lanes][2]
-  double *sPartial = sX + 2 * XBUF;  // [2][P pairs][32 particles]
-  double *sShift = sPartial + 2 * P * 32;
+  double *sPartial = sX + 2 * XBUF;  // [2][WAVES][32 particles]
+  double *sShift = sPartial + 2 * WAVES * 32;
   double *sBias = sShift + 16 * NB;
 
   for (int i = threadIdx.x; i < 16 * NB; i += THREADS) {
@@ -203,13 +211,12 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 
   // ---------------- compute waves ---------------------------------------------------------------
   const int p = lane & 15, h = lane >> 4;
-  // scalar: this wave's output pair q, its first tile and how many tiles it carries
-  const bool split = NB == 12 && w >= 4;
-  const int q = split ? 4 + ((w - 4) >> 1) : w;
-  const int tile0 = split ? (w - 4) & 1 : 0;
-  const int lo = q, hi = NB - 1 - q;
+  // scalar: this wave's output blocks (lo = -1: a single block, hi)
+  const int lo = wide_lo(NB, w), hi = wide_hi(NB, w);
+  const bool single = lo < 0;
+  constexpr int tile0 = 0;
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(frags), 0, (int)frag_bytes, 0x00020000);
-  const int wbyte0 = streams.byte_off[q];
+  const int wbyte0 = streams.byte_off[w];
   const int wlane = lane * 8;
   auto load_w = [&](int fi) -> double {  // fragment fi of this wave's stream
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, wlane, wbyte0 + fi * 512, 0));
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) w0[s][i] = load_w(s * 2 + i);
+    for (int i = 0; i < 2; ++i) w0[s][i] = single ? load_w(s) : load_w(s * 2 + i);  // (single: one fragment per k-step)
 
   __syncthreads();  // the first group is staged
   auto run = [&](auto tpw_tag) {
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       v4d init = v4d{0.0, 0.0, 0.0, 0.0};
-      if (!CENTRED) {  // C rows are output dims h + 4r of block cb
+      if (!CENTRED && (m == 1 || !single)) {  // C rows are output dims h + 4r of block cb
         const double *b = sBias + 16 * (m ? hi : lo) + h;
         init = v4d{b[0], b[4], b[8], b[12]};
       }
@@ -332,12 +339,13 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
     // i.e. fragments requested three k-blocks ahead at no register cost.  No gain -- 661..670 us
     // against 654..660 in the calibration run -- so the fragment latency is not what the two streams
     // cost each other.)
-    {
+    {  // (a single-block wave has no two-member phase: lo + 1 = 0)
       const bool odd = run_phase(std::integral_constant<int, 2>{}, 0, lo + 1, false);
       run_phase(std::integral_constant<int, 1>{}, lo + 1, hi + 1, odd);
     }
 
-    // partial sums of squares over this wave's two output blocks, per particle: slot [pair][tile][p]
+    // partial sums of squares over this wave's output blocks, per particle: slot [wave][tile][p]
+    // (an absent member's accumulator is zero)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       double qq = 0.0;
@@ -347,21 +355,20 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
         for (int r = 0; r < 4; ++r) qq = fma(acc[t][m][r], acc[t][m][r], qq);
       qq += __shfl_xor(qq, 16);
       qq += __shfl_xor(qq, 32);
-      if (h == 0) sPartial[(parity * P + q) * 32 + (tile0 + t) * 16 + p] = qq;
+      if (h == 0) sPartial[(parity * WAVES + w) * 32 + (tile0 + t) * 16 + p] = qq;
     }
     __syncthreads();  // partials visible; the loader has completed the other buffer
-    if (w == 0 && lane < 32) {  // fixed summation order over the pairs -> bitwise reproducible
-      const double *sp = sPartial + parity * P * 32 + lane;
+    if (w == 0 && lane < 32) {  // fixed summation order over the waves -> bitwise reproducible
+      const double *sp = sPartial + parity * WAVES * 32 + lane;
       double tot = sp[0];
 #pragma unroll
-      for (int k = 1; k < P; ++k) tot += sp[k * 32];
+      for (int k = 1; k < WAVES; ++k) tot += sp[k * 32];
       const long row = g * GP + lane;
       if (row < N) out[row] = finish_wide(tot, ep);
     }
   }
   };
-  if (split) run(std::integral_constant<int, 1>{});
-  else run(std::integral_constant<int, 2>{});
+  run(std::integral_constant<int, 2>{});
 }
 
 template <int NB>
@@ -369,9 +376,9 @@ static WideStreams wide_streams()
 {
   WideStreams st{};
   long off = 0;
-  for (int q = 0; q < wide_pairs(NB); ++q) {
-    st.byte_off[q] = (int)(off * 8);
-    off += wide_stream_frags(NB, q) * 64;
+  for (int w = 0; w < wide_waves(NB); ++w) {
+    st.byte_off[w] = (int)(off * 8);
+    off += wide_stream_frags(NB, w) * 64;
   }
   return st;
 }
