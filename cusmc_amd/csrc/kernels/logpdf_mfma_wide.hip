@@ -1,4 +1,4 @@
-// Batched MVN / Student-t log-density for large d: 128 < d <= 256, run as NB = 12 or 16 blocks of 16:
+// Batched MVN / Student-t log-density for large d: 128 < d <= 256, run as NB = ceil(d / 16) blocks of 16:
 // the regime where (X - mu) L^-T is a genuine dense GEMM and the kernel is bound by the f64 matrix
 // cores, not by HBM (d = 256: 2056 B and ~70 kflop per particle = 34 flop/B against a machine
 // balance of 9.8).  Same contract and same reference functions as kernels/logpdf_mfma_kernel.h:
@@ -45,30 +45,48 @@ namespace cusmc {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-__host__ __device__ constexpr int wide_pairs(int nb) { return nb / 2; }
-// EIGHT compute waves (two per SIMD: waves w and w + 4) for both block counts, each carrying its output
-// blocks for BOTH particle tiles of a group (every fragment it loads feeds two MFMAs).
-//   NB = 16: wave w owns the pair (w, 15 - w): 17 block-products per tile, the same for every wave.
-//   NB = 12: six pairs do not spread over four SIMDs (two SIMDs with four pair-tiles, two with two: the
-//   first mapping, 48.8 TFLOP/s at d = 192).  Waves 0..3 own the pairs (w, 11 - w) (13 block-products),
-//   waves 4..7 a single block each -- 7, 4, 6, 5 (8, 5, 7, 6 block-products): the SIMDs carry 21, 18, 20
-//   and 19 block-products per tile where 19.5 would be perfect.
+// EIGHT compute waves (two per SIMD: waves w and w + 4) whatever the block count NB = 9 .. 16, each
+// carrying up to two output blocks (lo < hi; lo = -1: a single block; hi = -1: none) for BOTH particle
+// tiles of a group, so that every fragment it loads feeds two MFMAs.  Output block cb costs cb + 1
+// block-products per tile; the blocks are dealt to the four SIMDs longest-first onto the least loaded
+// one (at most four per SIMD), and a SIMD's blocks to its two waves as (largest, smallest) and the
+// middle two.  NB = 16 comes out as 34 block-products per tile on every SIMD, NB = 12 as 21, 20, 19,
+// 18 where 19.5 would be perfect (six pair-waves would leave 26, 26, 13, 13: the first NB = 12 mapping,
+// 48.8 TFLOP/s at d = 192).
 __host__ __device__ constexpr int wide_waves(int nb) { return (void)nb, 8; }
 __host__ __device__ constexpr int wide_gp(int nb) { return (void)nb, 32; }  // particles per group
-// output blocks of wave w: (lo, hi), lo = -1 for a wave with a single block
-__host__ __device__ constexpr int wide_lo(int nb, int w) { return nb == 12 && w >= 4 ? -1 : w; }
-__host__ __device__ constexpr int wide_hi(int nb, int w)
+struct WideMap { int lo[8], hi[8]; };
+__host__ __device__ constexpr WideMap wide_map(int nb)
 {
-  return nb == 12 && w >= 4 ? (w == 4 ? 7 : w == 5 ? 4 : w == 6 ? 6 : 5) : nb - 1 - w;
+  WideMap m{};
+  for (int w = 0; w < 8; ++w) { m.lo[w] = -1; m.hi[w] = -1; }
+  int load[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0}, blk[4][4] = {};
+  for (int cb = nb - 1; cb >= 0; --cb) {  // longest first
+    int s = -1;
+    for (int k = 0; k < 4; ++k)
+      if (cnt[k] < 4 && (s < 0 || load[k] < load[s])) s = k;
+    blk[s][cnt[s]++] = cb;  // (descending within a SIMD)
+    load[s] += cb + 1;
+  }
+  for (int s = 0; s < 4; ++s) {
+    const int n = cnt[s];
+    if (n >= 1) m.hi[s] = blk[s][0];
+    if (n >= 2) m.hi[s + 4] = blk[s][1];
+    if (n == 3) m.lo[s] = blk[s][2];
+    if (n == 4) { m.lo[s] = blk[s][3]; m.lo[s + 4] = blk[s][2]; }
+  }
+  return m;
 }
+__host__ __device__ constexpr int wide_lo(int nb, int w) { return wide_map(nb).lo[w]; }
+__host__ __device__ constexpr int wide_hi(int nb, int w) { return wide_map(nb).hi[w]; }
 __host__ __device__ constexpr int wide_pi(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
 
-// Block count the kernel runs d with: 12 up to d = 192, 16 up to d = 256.  (d = 128 belongs to the
+// Block count the kernel runs d with: ceil(d / 16) = 9 .. 16.  (d = 128 belongs to the
 // tile kernel: 297 us against 382 us here for 1e6 particles -- at 8 blocks the split over waves
 // leaves each wave too little work per k-block to cover its fragment loads.)
-int mfma_wide_nb(int d) { return d <= 192 ? 12 : 16; }
+int mfma_wide_nb(int d) { return (d + 15) / 16; }
 
-// d = 192, 256 with 16-byte aligned rows run unpadded; every other d in (128, 256] and every
+// d = 144, 160, ..., 256 with 16-byte aligned rows run unpadded; every other d in (128, 256] and every
 // other alignment runs the padded variant (PAD: zero-padded factor, columns >= d masked to zero
 // where the compute waves pick their operands out of LDS).
 bool mfma_wide_supported(int d, const void *X, int64_t ldx)
@@ -86,6 +104,7 @@ static bool wide_needs_pad(int d, const void *X, int64_t ldx)
 static long wide_stream_frags(int nb, int w)
 {
   const int lo = wide_lo(nb, w), hi = wide_hi(nb, w);
+  if (hi < 0) return 0;  // (a wave without a block: NB < 8 never happens, but the map allows it)
   return lo < 0 ? 4L * (hi + 1) : 4L * (2 * (lo + 1) + (hi - lo));  // both up to kb = lo, then the high block alone
 }
 
@@ -115,7 +134,7 @@ void mfma_wide_pack_frags(const double *M, int d, double *frags)
       for (int s = 0; s < 4; ++s)
         for (int m = 0; m < 2; ++m) {
           const int cb = m ? hi : lo;
-          if (cb < kb) continue;  // (lower triangular; also skips the absent member lo = -1)
+          if (cb < kb) continue;  // (lower triangular; also skips an absent member, cb = -1)
           for (int l = 0; l < 64; ++l) {
             const int j = l & 15, h = l >> 4;
             frags[f * 64 + l] = M[(size_t)(16 * cb + j) * d + 16 * kb + wide_pi(s, h)];
@@ -212,7 +231,8 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
   // ---------------- compute waves ---------------------------------------------------------------
   const int p = lane & 15, h = lane >> 4;
   // scalar: this wave's output blocks (lo = -1: a single block, hi)
-  const int lo = wide_lo(NB, w), hi = wide_hi(NB, w);
+  constexpr WideMap map = wide_map(NB);
+  const int lo = map.lo[w], hi = map.hi[w];  // (w is wave-uniform: scalar loads from a constant table)
   const bool single = lo < 0;
   constexpr int tile0 = 0;
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(frags), 0, (int)frag_bytes, 0x00020000);
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       v4d init = v4d{0.0, 0.0, 0.0, 0.0};
-      if (!CENTRED && (m == 1 || !single)) {  // C rows are output dims h + 4r of block cb
+      if (!CENTRED && (m ? hi : lo) >= 0) {  // C rows are output dims h + 4r of block cb
         const double *b = sBias + 16 * (m ? hi : lo) + h;
         init = v4d{b[0], b[4], b[8], b[12]};
       }
@@ -447,8 +467,8 @@ hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int 
     if (!centred) return CUSMC_WPAD(nb, false, false);                                              \
     return has_shift ? CUSMC_WPAD(nb, true, true) : CUSMC_WPAD(nb, true, false);
   switch (mfma_wide_nb(d)) {
-    CUSMC_WIDE(12)
-    CUSMC_WIDE(16)
+    CUSMC_WIDE(9) CUSMC_WIDE(10) CUSMC_WIDE(11) CUSMC_WIDE(12)
+    CUSMC_WIDE(13) CUSMC_WIDE(14) CUSMC_WIDE(15) CUSMC_WIDE(16)
   }
 #undef CUSMC_WIDE
 #undef CUSMC_WPAD

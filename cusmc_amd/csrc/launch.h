@@ -59,7 +59,7 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
 
 // --- kernels/logpdf_mfma_wide.hip : 128 < d <= 256, output blocks split over the waves -----------
 bool mfma_wide_supported(int d, const void *X, int64_t ldx);
-int mfma_wide_nb(int d);  // 16-column blocks the wide kernel runs d with (8, 12 or 16)
+int mfma_wide_nb(int d);  // 16-column blocks the wide kernel runs d with: ceil(d / 16) = 9 .. 16
 size_t mfma_wide_frag_doubles(int nb);
 void mfma_wide_pack_frags(const double *M, int d, double *frags);
 hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int d, bool centred,
