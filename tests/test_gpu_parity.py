@@ -226,7 +226,7 @@ def test_tile_deal_boundaries(cs, oracle, d, N, dist):
     D.close()
 
 
-@pytest.mark.parametrize("d", [17, 24, 31, 40, 65, 81, 100, 127, 129, 144, 150, 191, 200, 255])
+@pytest.mark.parametrize("d", [17, 24, 31, 40, 65, 81, 100, 127, 129, 144, 150, 160, 170, 176, 191, 192, 200, 208, 220, 224, 239, 240, 255, 256])
 @pytest.mark.parametrize("dist", ["mvn", "mvt"])
 def test_padded_dimensions(cs, oracle, d, dist):
     """d not a multiple of 16 runs on the matrix cores with the factor zero-padded: every output
