@@ -6,13 +6,13 @@ namespace cusmc {
 
 int mfma_num_frags(int nb, bool tri) { return tri ? 4 * nb * (nb + 1) / 2 : 4 * nb * nb; }
 
-// d = 16, 32, ..., 128 with 16-byte aligned rows take the plain kernel; every other d in (16, 128]
+// d = 16, 32, ..., 176 with 16-byte aligned rows take the plain kernel; every other d in (16, 176]
 // and every other alignment the padded variant (PAD).  d < 16 stays with the generic kernel: a
 // single, mostly empty k-block would cost more loads than it saves.  A tile's per-lane byte offset
 // is kept in 32 bits.
 bool mfma_supported(int d, const void *X, int64_t ldx)
 {
-  return d >= 16 && d <= 128 && ldx < (1L << 24);
+  return d >= 16 && d <= kTileKernelMaxDim && ldx < (1L << 24);
 }
 static bool mfma_needs_pad(int d, const void *X, int64_t ldx)
 {
@@ -82,6 +82,15 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
     CUSMC_CASE(6)
     CUSMC_CASE(7)
     CUSMC_CASE(8)
+#if CUSMC_TILE_MAX_NB >= 9
+    CUSMC_CASE(9)
+#endif
+#if CUSMC_TILE_MAX_NB >= 10
+    CUSMC_CASE(10)
+#endif
+#if CUSMC_TILE_MAX_NB >= 11
+    CUSMC_CASE(11)
+#endif
   }
 #undef CUSMC_CASE
 #undef CUSMC_EPI

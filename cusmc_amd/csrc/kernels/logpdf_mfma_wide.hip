@@ -1,4 +1,4 @@
-// Batched MVN / Student-t log-density for large d: 128 < d <= 256, run as NB = ceil(d / 16) blocks of 16:
+// Batched MVN / Student-t log-density for large d: 176 < d <= 256, run as NB = ceil(d / 16) = 12 .. 16 blocks of 16:
 // the regime where (X - mu) L^-T is a genuine dense GEMM and the kernel is bound by the f64 matrix
 // cores, not by HBM (d = 256: 2056 B and ~70 kflop per particle = 34 flop/B against a machine
 // balance of 9.8).  Same contract and same reference functions as kernels/logpdf_mfma_kernel.h:
@@ -81,7 +81,7 @@ __host__ __device__ constexpr int wide_lo(int nb, int w) { return wide_map(nb).l
 __host__ __device__ constexpr int wide_hi(int nb, int w) { return wide_map(nb).hi[w]; }
 __host__ __device__ constexpr int wide_pi(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
 
-// Block count the kernel runs d with: ceil(d / 16) = 9 .. 16.  (d = 128 belongs to the
+// Block count the kernel runs d with: ceil(d / 16) (12 .. 16 in the library; the map below serves 9 .. 16).  (d <= 176 belongs to the
 // tile kernel: 297 us against 382 us here for 1e6 particles -- at 8 blocks the split over waves
 // leaves each wave too little work per k-block to cover its fragment loads.)
 int mfma_wide_nb(int d) { return (d + 15) / 16; }
@@ -93,7 +93,7 @@ bool mfma_wide_supported(int d, const void *X, int64_t ldx)
 {
   (void)X;
   // a group of <= 64 rows is addressed through one 32-bit buffer descriptor
-  return d > 128 && d <= 256 && ldx < (1L << 21);
+  return d > kTileKernelMaxDim && d <= 256 && ldx < (1L << 21);
 }
 static bool wide_needs_pad(int d, const void *X, int64_t ldx)
 {
@@ -467,8 +467,10 @@ hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int 
     if (!centred) return CUSMC_WPAD(nb, false, false);                                              \
     return has_shift ? CUSMC_WPAD(nb, true, true) : CUSMC_WPAD(nb, true, false);
   switch (mfma_wide_nb(d)) {
-    CUSMC_WIDE(9) CUSMC_WIDE(10) CUSMC_WIDE(11) CUSMC_WIDE(12)
-    CUSMC_WIDE(13) CUSMC_WIDE(14) CUSMC_WIDE(15) CUSMC_WIDE(16)
+#if CUSMC_TILE_MAX_NB < 11  // (calibration builds only: the tile kernel takes these in the library)
+    CUSMC_WIDE(9) CUSMC_WIDE(10) CUSMC_WIDE(11)
+#endif
+    CUSMC_WIDE(12) CUSMC_WIDE(13) CUSMC_WIDE(14) CUSMC_WIDE(15) CUSMC_WIDE(16)
   }
 #undef CUSMC_WIDE
 #undef CUSMC_WPAD

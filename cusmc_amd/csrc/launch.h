@@ -43,6 +43,17 @@ struct Epilogue {
 //   -- for d >= 16 rotated on the host to M = L (lower triangular), bias = Q^T W y with -W F = Q L:
 //   |z|^2 does not change and the matrix-core kernels only ever see triangular factors
 
+// Largest block count of the tile kernel (logpdf_mfma.hip): d <= 176.  Its factor lives in LDS from
+// NB = 5 up -- 135 KB at NB = 11, and NB = 12 (160 KB) no longer fits beside the rest; the wide kernel
+// (logpdf_mfma_wide.hip) serves 176 < d <= 256.  Where both can run the tile kernel wins (1e6 particles,
+// scripts/d128_ab.py: d = 144 380 against 517 us, d = 160 467 / 579, d = 176 547 / 636): a wave that owns
+// a whole particle tile reuses every factor fragment it reads from LDS for NB..1 block-products, the wide
+// kernel's waves fetch theirs from L2 for two.  (-DCUSMC_TILE_MAX_NB=8 restores the old split for A/B runs.)
+#ifndef CUSMC_TILE_MAX_NB
+#define CUSMC_TILE_MAX_NB 11
+#endif
+constexpr int kTileKernelMaxDim = 16 * CUSMC_TILE_MAX_NB;
+
 // --- kernels/logpdf_mfma.hip : d = 16*NB, v_mfma_f64_16x16x4_f64 -------------------------------
 // Number of 512-byte B fragments the kernel expects in `frags` (LDS image, kernel loop order).
 int mfma_num_frags(int nb, bool tri);

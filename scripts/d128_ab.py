@@ -12,7 +12,7 @@ import numpy as np, torch, cusmc_amd
 from scripts.logpdf_sweep import spd, timed
 ctx = cusmc_amd.api.default_context().use_torch_stream()
 g = torch.Generator(device="cuda").manual_seed(7)
-for d in (80, 96, 112, 128):
+for d in tuple(int(v) for v in os.environ.get("DIMS", "80,96,112,128").split(",")):
     N = 1_000_000
     X = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
     out = torch.empty(N, dtype=torch.float64, device="cuda")
