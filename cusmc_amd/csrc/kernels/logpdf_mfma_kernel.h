@@ -84,7 +84,7 @@ __device__ __forceinline__ double finish_epi(double q, const Epilogue &ep)
 // stay live across the tile loop, and at d = 64 the loop owns the whole register file (80 factor +
 // 96 operand + 32 accumulator VGPRs) -- with them hipcc spilled one operand pair and drained
 // vmcnt to reload it on every third tile.
-// PAD = true serves every other d in (16, 128] and every alignment: the factor is zero-padded to
+// PAD = true serves every other d in (16, 176] and every alignment: the factor is zero-padded to
 // 16*NB on the host, the first NB-1 k-blocks are loaded as usual (16-byte loads that need no more
 // than the rows' natural 8-byte alignment), and the last k-block is loaded element by element with
 // the column clamped into the row and the columns >= d replaced by zero -- never read from the
