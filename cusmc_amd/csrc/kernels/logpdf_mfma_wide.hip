@@ -87,8 +87,8 @@ __host__ __device__ constexpr int wide_pi(int s, int h) { return 2 * h + (s & 1)
 int mfma_wide_nb(int d) { return (d + 15) / 16; }
 
 // d = 144, 160, ..., 256 with 16-byte aligned rows run unpadded; every other d in (128, 256] and every
-// other alignment runs the padded variant (PAD: zero-padded factor, columns >= d masked to zero
-// where the compute waves pick their operands out of LDS).
+// other alignment runs the padded variant (PAD: zero-padded factor, columns >= d zeroed in the LDS staging
+// buffer by the loader wave).
 bool mfma_wide_supported(int d, const void *X, int64_t ldx)
 {
   (void)X;
@@ -218,11 +218,37 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
             if (t == TILES - 1 && h2 == 1) __builtin_amdgcn_s_sleep(8);
           }
     };
+    // PAD, d not a multiple of 16: the last k-block's columns >= d hold the next row's leading values (or
+    // whatever lies past the end of X): not this particle's, possibly not finite, so they must not reach
+    // the matrix cores even against a zero factor column.  The loader -- idle until the barrier anyway --
+    // waits for its DMA and overwrites them with zeros in the staging buffer; the compute waves then run
+    // the same instruction stream as the unpadded kernel (masking the operands there, behind a uniform
+    // branch per k-step, cost 16 - 21 % of the launch: the branch took the compiler's load scheduling and
+    // counted waits across the k-steps with it).
+    auto zero_tail = [&](double *buf) {
+      if constexpr (PAD) {
+        if (d_true == 16 * NB) return;  // (padded for alignment only)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int c0 = 16 * (NB - 1) + 2 * (lane >> 4);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) {
+            double *chunk = buf + (((NB - 1) * 2 + h2) * TILES + t) * 128 + 2 * lane;
+            if (c0 + 8 * h2 >= d_true) chunk[0] = 0.0;
+            if (c0 + 8 * h2 + 1 >= d_true) chunk[1] = 0.0;
+          }
+      }
+    };
     stage_group(blockIdx.x, sX);
+    zero_tail(sX);
     __syncthreads();
     int parity = 0;
     for (long g = blockIdx.x; g < num_groups; g += G, parity ^= 1) {
-      if (ABL != 2 && ABL != 3) stage_group(g + G, sX + (parity ^ 1) * XBUF);
+      if (ABL != 2 && ABL != 3) {
+        stage_group(g + G, sX + (parity ^ 1) * XBUF);
+        zero_tail(sX + (parity ^ 1) * XBUF);
+      }
       __syncthreads();
     }
     return;
@@ -312,16 +338,6 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
         double r[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) r[t] = xcur[s >> 1][t][s & 1];
-        if constexpr (PAD) {
-          // columns >= d of the padded k-blocks hold the next row's leading values (or zeros past
-          // the end of X): not this particle's, possibly not finite -- they must not reach the
-          // matrix cores even against a zero factor column
-          if (kb >= d_true / 16) {  // uniform
-            const bool keepc = 16 * kb + wide_pi(s, h) < d_true;
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) r[t] = keepc ? r[t] : 0.0;
-          }
-        }
         if (CENTRED && SHIFT) {
           const double sh = sShift[16 * kb + wide_pi(s, h)];
 #pragma unroll

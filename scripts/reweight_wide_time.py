@@ -5,7 +5,7 @@ import cusmc_amd
 from scripts.logpdf_sweep import spd, timed
 ctx = cusmc_amd.api.default_context().use_torch_stream()
 g = torch.Generator(device="cuda").manual_seed(7)
-for d in (128, 144, 160, 176, 192, 200, 224, 256):
+for d in tuple(int(v) for v in os.environ.get("DIMS", "128,144,160,176,192,200,224,256").split(",")):
     N = 64_000_000 // d
     X = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
     out = torch.empty(N, dtype=torch.float64, device="cuda")
