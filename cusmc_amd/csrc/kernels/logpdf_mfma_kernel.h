@@ -87,8 +87,9 @@ __device__ __forceinline__ double finish_epi(double q, const Epilogue &ep)
 // PAD = true serves every other d in (16, 176] and every alignment: the factor is zero-padded to
 // 16*NB on the host, the first NB-1 k-blocks are loaded as usual (16-byte loads that need no more
 // than the rows' natural 8-byte alignment), and the last k-block is loaded element by element with
-// the column clamped into the row and the columns >= d replaced by zero -- never read from the
-// next row (whose values are not this particle's and might not be finite) nor past the end of X.
+// the column clamped into the row (columns >= d read the particle's own last element, against a zero
+// factor column) -- never from the next row (whose values are not this particle's and might not be
+// finite) nor past the end of X.
 // ABL is for scripts/calib/ablate.hip only (0 in the library): 1 = no global loads inside the tile
 // loop, 2 = no MFMAs, 3 = no cross-lane reduction, 4 = clock stamps, 5 = 1 + 4.  It exists to
 // attribute time.
@@ -270,15 +271,13 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
   // unused): a branch around the prefetch would make hipcc's s_waitcnt placement assume the
   // no-prefetch path and wait for the prefetched loads at the head of every tile.
   // PAD: per-lane byte offsets of the last k-block's four elements (k = pi(s,h)), column clamped to
-  // d-1, for a full tile and for the last one; `keep[s]` = the column exists
+  // d-1, for a full tile and for the last one
   unsigned pad_off[4] = {0, 0, 0, 0}, pad_off_last[4] = {0, 0, 0, 0};
-  bool keep[4] = {true, true, true, true};
   if constexpr (PAD) {
     const int rem = d_true - 16 * (NB - 1);  // columns of the last block that exist: 1..16
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const int col = pi_k(s4, h);
-      keep[s4] = col < rem;
       const long cc = 16 * (NB - 1) + (col < rem ? col : rem - 1);
       pad_off[s4] = (unsigned)((long)p * ldx + cc) * 8u;
       pad_off_last[s4] = (unsigned)((long)(p < tail_rows ? p : tail_rows - 1) * ldx + cc) * 8u;
@@ -296,8 +295,12 @@ __global__ __launch_bounds__(mfma_threads<NB>()) void logpdf_mfma_kernel(
     if constexpr (PAD) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        const double v = *reinterpret_cast<const double *>(base + (t == last ? pad_off_last[s4] : pad_off[s4]));
-        a[NB - 1][s4 >> 1][s4 & 1] = keep[s4] ? v : 0.0;
+        // A column >= d reads THIS particle's own last element instead (clamped address) and meets a
+        // zero column of the padded factor: 0 for every finite particle, and a particle holding a NaN /
+        // Inf there is non-finite in the exact result too.  No select -- on the loaded value it made
+        // the wave wait for these loads, the youngest in flight, the moment they were issued, and with
+        // them for the whole prefetched tile (7 - 18 % of a launch).
+        a[NB - 1][s4 >> 1][s4 & 1] = *reinterpret_cast<const double *>(base + (t == last ? pad_off_last[s4] : pad_off[s4]));
       }
     }
   };
