@@ -140,8 +140,10 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int col = pm_pi(s, h);
-          const double v = row[16 * (NB - 1) + (col < rem ? col : rem - 1)];
-          xg[NB - 1][s >> 1][s & 1] = col < rem ? v : 0.0;
+          // (a column >= d reads the ancestor's own last element against a zero column of the padded G:
+          // no select on the loaded value, which would make the wave wait for the gather before the RNG
+          // below had a chance to hide it)
+          xg[NB - 1][s >> 1][s & 1] = row[16 * (NB - 1) + (col < rem ? col : rem - 1)];
         }
       }
     }
