@@ -113,12 +113,14 @@ __device__ __forceinline__ double finish_epi(double q, const Epilogue &ep)
 //     chunk request cost its wave a full s_waitcnt vmcnt(0), i.e. the HBM latency under load with
 //     nothing prefetched behind it, and 256 scattered 128 KB streams use HBM less well than one
 //     window.
-//   * Inside a workgroup the waves pull their next tile through one packed 64-bit LDS word
-//     {end, next} -- a single ds_add_rtn_u64 per tile.  Static round-robin over WAVES loses ~10 %:
+//   * Inside a workgroup the waves pull their next ROUND from one LDS counter (round k of workgroup b
+//     is tile b + k G) -- a single ds_add_rtn_u32 per tile.  Static round-robin over WAVES loses ~10 %:
 //     the older of two waves on a SIMD wins issue arbitration, finishes its share early and leaves
 //     the younger one to run alone (measured: 78 us vs 87 us wave lifetimes at d = 64).
 //   * Nothing is dynamic ACROSS workgroups, although workgroup lifetimes differ by ~8 % from launch
-//     to launch and the launch ends ~5 us after its average workgroup.  Two queued tails were built
+//     to launch -- at random: the slow ones are not the same from one launch to the next (rank
+//     correlation 0.07, scripts/calib/ablate.hip persist) -- and the launch ends ~5 us after its average
+//     workgroup.  Two queued tails were built
 //     and measured against the pure deal on one box each (scripts/calib/ablate.hip):
 //       - last eighth of the rounds from ONE counter, chunks of 16 then 8 tiles, scalar
 //         s_atomic_add ... glc draws (they return through lgkmcnt, so the drawing wave keeps its
