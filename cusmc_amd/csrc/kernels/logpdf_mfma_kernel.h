@@ -1,4 +1,5 @@
-// Batched multivariate Normal / Student-t log-density for d = 16*NB on gfx950, fp64.
+// Batched multivariate Normal / Student-t log-density for 16 <= d <= 176 (NB = ceil(d/16) <= 11 blocks) on
+// gfx950, fp64.
 //
 // Replaces the reference's three-launch pdf pipeline (mvn_pdf_kernel_y_minus_Fmu ->
 // mvn_pdf_kernel_Einv_alpha -> mvn_pdf_kernel, src/mvn_dist.cu.cpp:455-668, and the mvt twins,
@@ -19,14 +20,15 @@
 //              values of a block with two 16-byte loads, 64 contiguous bytes per particle per
 //              load instruction: X goes HBM -> VGPR once, coalesced, with no LDS round trip.
 //   A operand  lane (j = lane&15, h) holds M[16*cb + j][16*kb + pi(s,h)]: the factor, packed on
-//              the host in exactly this order (mfma_pack_frags) and staged ONCE per workgroup in
-//              registers (triangular, d <= 64: 80 VGPRs at d = 64) or, for the dense / large
-//              forms, staged once per workgroup in LDS and read one k-step ahead of its use.
+//              the host in exactly this order (mfma_pack_frags), staged ONCE per workgroup in LDS
+//              and from there kept in registers for the whole kernel (d <= 64: 80 VGPRs at d = 64)
+//              or, for the larger forms, read from LDS one k-step ahead of its use.
 //   C/D        C = M R^T: lane (p, h), register r  ->  output dim 16*cb + h + 4r of PARTICLE p.
 //              A lane only ever holds one particle's outputs, so the row sum of squares is 16
 //              in-lane FMAs plus one 4-lane reduction over h -- not a 16-lane reduction of four
 //              values, which is what the transposed product costs.
-//   Epilogue   lanes 0..15 finish particles 0..15 of the tile and store one 128-byte line.
+//   Epilogue   lanes 0..15 finish particles 0..15 of the tile and store one 128-byte line (Student-t:
+//              once per four tiles, on all 64 lanes).
 //
 // Roofline: 8d + 8 algorithmic bytes per particle; at d = 64 the kernel needs 40
 // MFMAs of 2048 flop per 16 particles.
