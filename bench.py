@@ -13,7 +13,15 @@ reported as `mh_steps_per_s`.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract: the task statement; roofline terms: DESIGN.md).
+Both forms run N ranks.  Started WITHOUT a launcher (`WORLD_SIZE` unset) and with --gpus N > 1, this
+process never touches the GPU: it starts `torch.distributed.run` with N fresh child ranks and exits
+with their code.  Under a launcher, `--gpus` must equal WORLD_SIZE (exit code 2 otherwise), so a
+mismatch can no longer measure one GPU and call it N.
+
+Prints ONE JSON line on rank 0 (contract: the task statement; roofline terms: DESIGN.md).  Beyond the
+contract's keys the line carries `strong` (fixed-total-work legs: the headline's 1e6 x 64 and
+BASELINE configs[4]'s 4e6 x 256 split over the ranks), `mh` (configs[1], weight all-gather timed) and
+`filter_step` (one sharded bootstrap-filter step with its two exchanges timed).
 """
 import argparse
 import json
@@ -32,6 +40,10 @@ D = 64
 ALGO_BYTES_PER_EVAL = 8 * D + 8  # read the particle once, write one log-density
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MH_N, MH_B, MH_D = 100_000, 1000, 32
+EXPECTED_KERNEL = "cusmc::logpdf_mfma_kernel<4, true, false, 0, 1, false>"
+C5_N, C5_D = 4_000_000, 256      # BASELINE configs[4]: d=256 MVN, 4e6 particles over the node
+F64_MFMA_PEAK_TFLOPS = 78.6      # public spec; measured 77.7 (profiles/r01_calibration.txt)
+PF_N = 1_000_000                 # BASELINE configs[2]: particle filter, 1e6 particles
 
 
 def make_sigma(d, seed):
@@ -69,7 +81,7 @@ def collect_hbm_traffic(n, d, kernel_substr="logpdf_mfma"):
     rocprof = "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None
-    total = {}
+    total, names = {}, set()
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
@@ -83,11 +95,13 @@ def collect_hbm_traffic(n, d, kernel_substr="logpdf_mfma"):
                         for row in csv.DictReader(f):
                             if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
                                 vals.append(float(row["Counter_Value"]))
+                                names.add(row["Kernel_Name"])
                 if not vals:
                     return None
                 total[counter] = sum(vals) / len(vals) * 1024.0
         return {"fetch_bytes": 2.0 * total["FETCH_SIZE"], "write_bytes": total["WRITE_SIZE"],
-                "hbm_bytes": 2.0 * total["FETCH_SIZE"] + total["WRITE_SIZE"]}
+                "hbm_bytes": 2.0 * total["FETCH_SIZE"] + total["WRITE_SIZE"],
+                "kernel": " | ".join(sorted(n.split("(")[0] for n in names))}
     except Exception as e:  # profiler missing / refused: report null, never a guess
         sys.stderr.write("bench: PMC traffic pass unavailable (%s)\n" % e)
         return None
@@ -125,6 +139,27 @@ def cpu_baseline(d, budget_s=12.0):
             "hoisted_factor_value": Xh.shape[0] / dth}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks through
+    torch.distributed.run as a CHILD process (never an exec: this process may not have touched the
+    GPU, but the rule on this pool is child processes only) and pass its exit code on."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_pmc:
+        cmd.append("--no-pmc")
+    if args.no_cpu:
+        cmd.append("--no-cpu")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     if os.environ.get("CUSMC_PMC_CHILD"):
         n, d, launches = (int(v) for v in os.environ["CUSMC_PMC_CHILD"].split(","))
@@ -139,9 +174,18 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.stderr.write("bench: --gpus must be >= 1\n")
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)  # the parent never touches the GPU; the ranks are fresh child processes
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench: --gpus %d but WORLD_SIZE is %d: refusing to report one as the other\n"
+                         % (args.gpus, world))
+        return 2
 
     traffic = None
     if world == 1 and not args.no_pmc:
@@ -253,6 +297,76 @@ def main():
     except Exception as exc:  # noqa: BLE001
         mh = {"steps_per_s": None, "error": repr(exc)}
 
+    def timed_max(fn, reps, warm=3):
+        """seconds per repetition of fn(), barrier + synchronize on both sides, MAX over ranks"""
+        for _ in range(warm):
+            fn()
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        tt = torch.tensor([(time.perf_counter() - t_) / reps], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    # Strong scaling (fixed TOTAL work split over the ranks, no data-path collective): the headline's
+    # 1e6 x 64 batch, and BASELINE configs[4]'s 4e6 x 256 (MFMA-bound: reported against the f64 matrix peak).
+    strong = None
+    try:
+        from cusmc_amd import sharding
+        _, cnt = sharding.shard_range(N_PER_GPU, rank, world)
+        Xs, outs = X[:cnt], out[:cnt]
+        s_head = timed_max(lambda: mvn.pdf_dev(Xs, outs), max(args.steps, 200), warm=50)
+        strong = {"headline_1e6x64": {"total_particles": N_PER_GPU, "particles_per_gpu": cnt, "evals_per_s": N_PER_GPU / s_head,
+                                      "us_per_launch": s_head * 1e6,
+                                      "hbm_frac_per_gpu": cnt * ALGO_BYTES_PER_EVAL / s_head / 1e9 / HBM_PEAK_GBS}}
+        _, cnt5 = sharding.shard_range(C5_N, rank, world)
+        X5 = torch.randn(cnt5, C5_D, dtype=torch.float64, device="cuda", generator=g)
+        out5 = torch.empty(cnt5, dtype=torch.float64, device="cuda")
+        d256 = cusmc_amd.MultiVariateNormalDistribution(np.zeros(C5_D), make_sigma(C5_D, 5))
+        s5 = timed_max(lambda: d256.pdf_dev(X5, out5), 10)
+        nb = C5_D // 16
+        flop5 = 2.0 * nb * (nb + 1) * 2048 / 16  # per particle: 2 NB (NB+1) MFMAs of 2048 flop per 16 particles
+        strong["c5_4e6x256"] = {"total_particles": C5_N, "particles_per_gpu": cnt5, "evals_per_s": C5_N / s5,
+                                "ms_per_pass": s5 * 1e3, "bound": "mfma",
+                                "tflops_per_gpu": cnt5 * flop5 / s5 / 1e12,
+                                "mfma_frac_per_gpu": cnt5 * flop5 / s5 / 1e12 / F64_MFMA_PEAK_TFLOPS}
+        d256.close()
+        del X5, out5
+    except Exception as exc:  # noqa: BLE001
+        strong = {"error": repr(exc), "partial": strong}
+
+    # One bootstrap-filter time step with the particles sharded (BASELINE configs[2]: 1e6 particles in all):
+    # all-gather of w_{t-1}, resample, all-to-all of the ancestor rows, propagate, reweight -- both
+    # exchanges inside the timed region; the all-gather-of-x form of round 1 beside it.
+    filt = None
+    try:
+        from cusmc_amd import sharding
+        filt = {}
+        for dd in (2, 64):
+            I = np.eye(dd)
+            Tf = 6
+            Yf = np.cumsum(0.05 * np.random.default_rng(3).standard_normal((dd, Tf)), axis=1)
+            model = (Yf, np.zeros(dd), I, I, I, 0.001 * I, 0.001 * I)
+            ini, res, mov, obs = sharding.gpu_filter_callables_exchange(*model, seed=11, ctx=mvn.ctx)
+            ini2, stp, obs2 = sharding.gpu_filter_callables(*model, seed=11, ctx=mvn.ctx)
+            st = {}
+            sharding.run_filter_sharded(PF_N, 2, ini, resample_fn=res, move_fn=mov)  # warm
+            s_x = timed_max(lambda: sharding.run_filter_sharded(PF_N, Tf, ini, resample_fn=res, move_fn=mov, stats=st), 1, warm=0)
+            s_g = timed_max(lambda: sharding.run_filter_sharded(PF_N, Tf, ini2, stp), 1, warm=1)
+            filt["d%d" % dd] = {"N_total": PF_N, "steps": Tf - 1,
+                                "ms_per_step_row_exchange": s_x / (Tf - 1) * 1e3,
+                                "ms_per_step_allgather_x": s_g / (Tf - 1) * 1e3,
+                                "bytes_in_per_step_row_exchange": {k: v / (Tf - 1) for k, v in st.items()},
+                                "bytes_in_per_step_allgather_x": (PF_N - sharding.shard_range(PF_N, rank, world)[1]) * 8 * (dd + 1)
+                                if world > 1 else 0}
+            obs.close()
+            obs2.close()
+    except Exception as exc:  # noqa: BLE001
+        filt = {"error": repr(exc), "partial": filt}
+
     # The CPU leg is the only place bench.py touches oracle/: it times the reference-faithful port
     # and, while it has it loaded, checks the sample of the GPU's outputs against it.
     cpu, parity = None, None
@@ -289,15 +403,23 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic["hbm_bytes"],
                          "algorithmic_bytes_per_launch": N_PER_GPU * ALGO_BYTES_PER_EVAL,
-                         "kernel": "cusmc::logpdf_mfma_kernel<4, true, false, 0, 1, false>", "kernel_ms": kernel_ms,
+                         # the name the PMC pass matched; without that pass, the instantiation this
+                         # workload dispatches to (logpdf_mfma.hip: NB = 4, centred, no shift, MVN epilogue)
+                         "kernel": traffic["kernel"] if traffic else EXPECTED_KERNEL,
+                         "kernel_name_source": "rocprofv3 counter_collection.csv" if traffic else "expected (no PMC pass)",
+                         "kernel_ms": kernel_ms,
                          "frac_of_measured_copy_peak": achieved / 6290.0},
             "cpu_baseline": cpu,
             "mh_steps_per_s": None if mh is None else mh.get("steps_per_s"),
             "mh": mh,
+            "strong": strong,
+            "filter_step": filt,
+            "ranks": world if world == 1 else int(dist.get_world_size()),
+            "backend": "single process" if world == 1 else dist.get_backend(),
             "parity_max_rel_err_vs_oracle": parity,
         }
         if traffic is not None:
-            line["roofline"]["traffic_detail"] = traffic
+            line["roofline"]["traffic_detail"] = {k: v for k, v in traffic.items() if k != "kernel"}
         print(json.dumps(line), flush=True)
     mvn.close()
     if world > 1:
@@ -305,4 +427,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

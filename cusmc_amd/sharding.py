@@ -76,23 +76,77 @@ def gather_final(a_local, n_total, group=None):
     return all_gather_ragged(a_local, n_total, group)
 
 
-def run_filter_sharded(N, T, init_fn, step_fn, group=None):
+def _all_to_all(out, inp, out_splits, in_splits, group=None):
+    """all_to_all_single; gloo has no device path for it, so a rehearsal on CUDA tensors (all ranks on one
+    GPU over gloo) stages through the host -- the RCCL path never does."""
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=group)
+    return out
+
+
+def exchange_rows(x_local, a_local, n_total, group=None, stats=None):
+    """x_full[a_local[i]] for this rank's ancestors WITHOUT gathering x_full: every rank asks the owner
+    of each ancestor for that row (one all-to-all of indices, 4 bytes each) and gets the rows back (one
+    all-to-all of rows).  Per rank and step that is count * (R-1)/R rows in -- N/R of them -- where the
+    all-gather of x_{t-1} brought in all N: 56 MB instead of 448 MB at N = 1e6, d = 64, R = 8
+    (1.75 instead of 14 MB at d = 2).  x_local: this rank's rows [first, first+count) of x_{t-1};
+    a_local: int32/int64 GLOBAL ancestor indices of this rank's particles.  Returns count x d rows in
+    the order of a_local.  `stats`, if given, accumulates the bytes this rank sent and received."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    counts = shard_counts(n_total, world)
+    first = sum(counts[:rank])
+    if world == 1:
+        return x_local[a_local.long()]
+    dev = x_local.device
+    bounds = torch.tensor([sum(counts[:k + 1]) for k in range(world - 1)], dtype=torch.int64, device=dev)
+    a64 = a_local.to(torch.int64)
+    owner = torch.bucketize(a64, bounds, right=True)         # owner(j) = #{k : j >= first_{k+1}}
+    order = torch.argsort(owner, stable=True)
+    want = a64[order].to(torch.int32)                        # grouped by owner, 4 bytes per index
+    send_n = torch.bincount(owner, minlength=world)
+    recv_n = torch.empty_like(send_n)
+    _all_to_all(recv_n, send_n, None, None, group)           # how many rows each peer asks of me
+    send_l, recv_l = send_n.tolist(), recv_n.tolist()        # (host sync: the split sizes are data)
+    asked = torch.empty(sum(recv_l), dtype=torch.int32, device=dev)
+    _all_to_all(asked, want, recv_l, send_l, group)
+    rows_out = x_local[(asked.to(torch.int64) - first)]      # the rows my peers asked for, in their order
+    rows_in = torch.empty((sum(send_l),) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=dev)
+    _all_to_all(rows_in, rows_out, send_l, recv_l, group)
+    out = torch.empty_like(rows_in)
+    out[order] = rows_in
+    if stats is not None:
+        row_b = x_local[0].numel() * x_local.element_size() if x_local.shape[0] else 0
+        off = sum(send_l) - send_l[rank]
+        stats["index_bytes_out"] = stats.get("index_bytes_out", 0) + 4 * off
+        stats["row_bytes_in"] = stats.get("row_bytes_in", 0) + row_b * off
+        stats["row_bytes_out"] = stats.get("row_bytes_out", 0) + row_b * (sum(recv_l) - recv_l[rank])
+    return out
+
+
+def run_filter_sharded(N, T, init_fn, step_fn=None, group=None, resample_fn=None, move_fn=None, stats=None):
     """The bootstrap filter's time loop (MCMC(), src/mcmc.cpp:292-308) with the particles sharded
     over the ranks -- the exact algorithm, not an island filter:
 
         x_0, w_0 = init_fn(first, count)                         this rank's rows of step 0
         for t = 1 .. T-1:
-            w_full = all-gather(w_{t-1});  X_full = all-gather(x_{t-1})
-            a_t, x_t, w_t = step_fn(t, w_full, X_full, first, count)   this rank's rows of step t
+            w_full = all-gather(w_{t-1})                         8 N bytes: every chain reads w[j] anywhere
+            a_t    = resample_fn(t, w_full, first, count)        this rank's chains (global indices)
+            x_anc  = exchange_rows(x_{t-1}, a_t)                 only the N/R rows its ancestors name
+            x_t, w_t = move_fn(t, x_anc, first, count)           propagate + reweight, local
 
-    Chain i reads w_{t-1}[j] for arbitrary j and particle i reads x_{t-1}[a_i] from anywhere, so
-    both vectors are gathered whole once per step (8 N and 8 N d bytes: 8 + 16 MB at N = 1e6,
-    d = 2); everything else is local and keyed by the GLOBAL particle index, so the concatenated
-    shards equal the single-process run.  Returns this rank's (X [T, count, d], w [T, count],
-    a [T, count]) -- ancestors of step 0 are zero, as in cusmc_pf_run_host.
+    Everything is keyed by the GLOBAL particle index, so the concatenated shards equal the
+    single-process run bit for bit.  Returns this rank's (X [T, count, d], w [T, count], a [T, count])
+    -- ancestors of step 0 are zero, as in cusmc_pf_run_host.
 
-    The compute is passed in (gpu_filter_callables() builds it over cusmc_pf_step_dev) so that the
-    CPU tests can drive the same loop with stand-ins."""
+    Legacy form (step_fn given): x_{t-1} is all-gathered whole every step (8 N d bytes) and
+    step_fn(t, w_full, X_full, first, count) does the rest.  Kept for A/B timing of the two exchanges.
+
+    The compute is passed in (gpu_filter_callables() builds it over the C ABI) so that the CPU tests can
+    drive the same loop with stand-ins."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     first, count = shard_range(N, rank, world)
@@ -102,8 +156,17 @@ def run_filter_sharded(N, T, init_fn, step_fn, group=None):
     X_hist, w_hist, a_hist = [x], [w], [torch.zeros(count, dtype=torch.int32, device=x.device)]
     for t in range(1, T):
         w_full = all_gather_ragged(w, N, group) if world > 1 else w
-        X_full = all_gather_ragged(x, N, group) if world > 1 else x
-        a, x, w = step_fn(t, w_full, X_full, first, count)
+        if stats is not None and world > 1:
+            stats["weight_bytes_in"] = stats.get("weight_bytes_in", 0) + 8 * (N - count)
+        if step_fn is not None:
+            X_full = all_gather_ragged(x, N, group) if world > 1 else x
+            if stats is not None and world > 1:
+                stats["row_bytes_in"] = stats.get("row_bytes_in", 0) + (N - count) * x[0].numel() * 8
+            a, x, w = step_fn(t, w_full, X_full, first, count)
+        else:
+            a = resample_fn(t, w_full, first, count)
+            x_anc = exchange_rows(x, a, N, group, stats) if world > 1 else x[a.long()]
+            x, w = move_fn(t, x_anc, first, count)
         X_hist.append(x)
         w_hist.append(w)
         a_hist.append(a)
@@ -140,3 +203,39 @@ def gpu_filter_callables(Y, m0, C0, F, G, V, W, df=0.0, distribution="mvn", B=10
         return a, x, w
 
     return init_fn, step_fn, obs
+
+
+def gpu_filter_callables_exchange(Y, m0, C0, F, G, V, W, df=0.0, distribution="mvn", B=10, seed=0, compat=False,
+                                  ctx=None):
+    """init_fn / resample_fn / move_fn for run_filter_sharded's row-exchange form: resample ->
+    (exchange) -> propagate -> reweight through the three separate C-ABI entry points, which give the
+    same numbers as the fused step (tests/test_gpu_parity.py::test_fused_step_equals_three_launches) and
+    hence as cusmc_pf_run_host.  Returns (init_fn, resample_fn, move_fn, obs)."""
+    import numpy as np
+
+    from . import api
+    init_fn, _, obs = gpu_filter_callables(Y, m0, C0, F, G, V, W, df, distribution, B, seed, compat, ctx)
+    ctx = obs.ctx
+    Y = np.asarray(Y, dtype=np.float64)
+    d = Y.shape[0]
+    F, G, W = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (F, G, W))
+    Qw = api.eigenSolver(W)
+    scale = api.SQRT3 if compat else 1.0
+    ident = {}
+
+    def resample_fn(t, w_full, first, count):
+        a = torch.empty(count, dtype=torch.int32, device="cuda")
+        api.Sampler.metropolis_hastings_dev(w_full, a, B=B, t=t, seed=seed, first=first, ctx=ctx)
+        return a
+
+    def move_fn(t, x_anc, first, count):
+        if count not in ident:
+            ident[count] = torch.arange(count, dtype=torch.int32, device="cuda")
+        x = torch.empty(count, d, dtype=torch.float64, device="cuda")
+        w = torch.empty(count, dtype=torch.float64, device="cuda")
+        api.propagate_dev(x_anc.contiguous(), ident[count], G, Qw, x, kind=distribution, nu=df, scale=scale, seed=seed,
+                          step=t, first=first, ctx=ctx)
+        obs.reweight_dev(x, Y[:, t], F, w, log=False)
+        return x, w
+
+    return init_fn, resample_fn, move_fn, obs

@@ -817,7 +817,7 @@ def test_cpp_host_mirror(cs):
     assert "all checks passed" in r.stdout
 
 
-def _sharded_gpu_worker(rank, world, port, N, d, T, tmp):
+def _sharded_gpu_worker(rank, world, port, N, d, T, tmp, exchange=False):
     import os
     import sys
     import torch
@@ -826,11 +826,18 @@ def _sharded_gpu_worker(rank, world, port, N, d, T, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)  # rehearsal: both ranks on the one GPU of the test box
-    from cusmc_amd.sharding import gather_final, gpu_filter_callables, run_filter_sharded
+    from cusmc_amd.sharding import gather_final, gpu_filter_callables, gpu_filter_callables_exchange, run_filter_sharded
     I = np.eye(d)
     Y = np.cumsum(0.1 * np.random.default_rng(5).standard_normal((d, T)), axis=1)
-    init_fn, step_fn, obs = gpu_filter_callables(Y, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, 0.0, "mvn", B=10, seed=21)
-    Xl, wl, al = run_filter_sharded(N, T, init_fn, step_fn)
+    model = (Y, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, 0.0, "mvn")
+    if exchange:
+        init_fn, resample_fn, move_fn, obs = gpu_filter_callables_exchange(*model, B=10, seed=21)
+        stats = {}
+        Xl, wl, al = run_filter_sharded(N, T, init_fn, resample_fn=resample_fn, move_fn=move_fn, stats=stats)
+        assert stats["row_bytes_in"] <= Xl.shape[1] * d * 8 * (T - 1)  # never more than its own N/R rows per step
+    else:
+        init_fn, step_fn, obs = gpu_filter_callables(*model, B=10, seed=21)
+        Xl, wl, al = run_filter_sharded(N, T, init_fn, step_fn)
     torch.cuda.synchronize()
     Xf = gather_final(Xl.permute(1, 0, 2).contiguous().cpu(), N).permute(1, 0, 2)
     wf = gather_final(wl.t().contiguous().cpu(), N).t()
@@ -843,11 +850,14 @@ def _sharded_gpu_worker(rank, world, port, N, d, T, tmp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,d", [(5003, 2), (3001, 16)])
-def test_sharded_filter_on_gpu_equals_run(cs, tmp_path, N, d):
+@pytest.mark.parametrize("N,d,exchange", [(5003, 2, False), (3001, 16, False), (5003, 2, True), (3001, 16, True),
+                                          (2003, 64, True)])
+def test_sharded_filter_on_gpu_equals_run(cs, tmp_path, N, d, exchange):
     """The multi-GPU filter path end to end (two ranks rehearsed on one device, gloo): shards
-    computed by cusmc_pf_step_dev with global Philox indices, weights and states all-gathered every
-    step -- the concatenated history is bitwise the single-process cusmc_pf_run_host result."""
+    computed with global Philox indices -- the concatenated history is bitwise the single-process
+    cusmc_pf_run_host result.  exchange = False: weights and states all-gathered every step, one
+    cusmc_pf_step_dev per rank; exchange = True: weights all-gathered, only the ancestor rows fetched
+    from their owners (all-to-all), resample / propagate / reweight through their own entry points."""
     import socket
     import torch.multiprocessing as mp
     T = 5
@@ -855,7 +865,7 @@ def test_sharded_filter_on_gpu_equals_run(cs, tmp_path, N, d):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     tmp = str(tmp_path / "pf.npz")
-    mp.spawn(_sharded_gpu_worker, args=(2, port, N, d, T, tmp), nprocs=2, join=True)
+    mp.spawn(_sharded_gpu_worker, args=(2, port, N, d, T, tmp, exchange), nprocs=2, join=True)
     got = np.load(tmp)
     I = np.eye(d)
     res = cs.run(N, d, T, got["Y"], np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn",

@@ -124,3 +124,73 @@ def test_two_rank_sharded_filter_equals_single_process(tmp_path, oracle):
     Xo, wo, ao = oracle.pf_run(got["Y"], N, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, "mvn", 0.0, B=10, seed=9)
     assert np.array_equal(got["a"][1:], ao[1:])
     assert np.allclose(got["X"], Xo, atol=1e-12) and np.allclose(got["w"], wo, rtol=1e-10)
+
+
+def _exchange_worker(rank, world, port, N, d, T, tmp):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cusmc_amd.sharding import exchange_rows, gather_final, run_filter_sharded, shard_range
+    from oracle import oracle as O
+    first, count = shard_range(N, rank, world)
+
+    # (1) exchange_rows alone: arbitrary (repeated, own and foreign) ancestors
+    rng = np.random.default_rng(77)
+    X_full = rng.standard_normal((N, d))
+    a_full = rng.integers(0, N, size=N)
+    a_full[::7] = a_full[0]  # heavy repeats, as after a resample
+    stats = {}
+    got = exchange_rows(torch.from_numpy(X_full[first:first + count].copy()),
+                        torch.from_numpy(a_full[first:first + count].astype(np.int32)), N, stats=stats)
+    assert np.array_equal(got.numpy(), X_full[a_full[first:first + count]])
+    foreign = int(np.sum((a_full[first:first + count] < first) | (a_full[first:first + count] >= first + count)))
+    assert stats["row_bytes_in"] == foreign * d * 8 and stats["index_bytes_out"] == foreign * 4
+
+    # (2) the filter loop in its exchange form, the oracle as the per-step compute
+    I = np.eye(d)
+    rng = np.random.default_rng(5)
+    Y = np.cumsum(0.1 * rng.standard_normal((T, d)), axis=0)
+    G, Qw, Q0 = 0.9 * I, O.eigen_sqrt(0.1 * I), O.eigen_sqrt(I)
+    V = 0.5 * I
+
+    def init_fn(f, c):
+        X0, _ = O.initialize(N, np.zeros(d), Q0, "mvn", 0.0, 1.0, seed=9, step=0)
+        return torch.from_numpy(X0[f:f + c]), None
+
+    def resample_fn(t, w_full, f, c):
+        return torch.from_numpy(O.metropolis(w_full.numpy(), 10, 9, step=t)[f:f + c].astype(np.int32))
+
+    def move_fn(t, x_anc, f, c):
+        # the oracle keys its draws by the row index: place this rank's gathered rows at their global
+        # positions and propagate with identity ancestors
+        Xp = np.zeros((N, d))
+        Xp[f:f + c] = x_anc.numpy()
+        X = O.propagate(Xp, np.arange(N), G, Qw, "mvn", 0.0, 1.0, seed=9, step=t)[f:f + c].copy()
+        return torch.from_numpy(X), torch.from_numpy(O.reweight(X, Y[t], I, V, "mvn", 0.0))
+
+    fstats = {}
+    Xl, wl, al = run_filter_sharded(N, T, init_fn, resample_fn=resample_fn, move_fn=move_fn, stats=fstats)
+    assert fstats["weight_bytes_in"] == 8 * (N - count) * (T - 1)
+    assert fstats["row_bytes_in"] <= count * d * 8 * (T - 1)  # never more than its own N/R rows per step
+    Xf = gather_final(Xl.permute(1, 0, 2).contiguous(), N).permute(1, 0, 2)
+    wf = gather_final(wl.t().contiguous(), N).t()
+    af = gather_final(al.t().contiguous(), N).t()
+    if rank == 0:
+        np.savez(tmp, X=Xf.numpy(), w=wf.numpy(), a=af.numpy(), Y=Y)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_filter_row_exchange_equals_single_process(tmp_path, oracle, world):
+    """The exchange form of run_filter_sharded (all-gather of w, all-to-all of only the ancestor rows) over
+    gloo with 2 and 3 ranks (ragged shards): the gathered history equals the oracle's single-process filter."""
+    N, d, T = 203, 2, 6
+    tmp = str(tmp_path / "pfx.npz")
+    mp.spawn(_exchange_worker, args=(world, _free_port(), N, d, T, tmp), nprocs=world, join=True)
+    got = np.load(tmp)
+    I = np.eye(d)
+    Xo, wo, ao = oracle.pf_run(got["Y"], N, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, "mvn", 0.0, B=10, seed=9)
+    assert np.array_equal(got["a"][1:], ao[1:])
+    assert np.allclose(got["X"], Xo, atol=1e-12) and np.allclose(got["w"], wo, rtol=1e-10)
