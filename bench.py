@@ -295,6 +295,8 @@ def main():
                           % (world, MH_N, MH_B, MH_D, "" if world == 1 else "; all-gather of the weight shards timed")}
         d32.close()
     except Exception as exc:  # noqa: BLE001
+        if world > 1:
+            raise
         mh = {"steps_per_s": None, "error": repr(exc)}
 
     def timed_max(fn, reps, warm=3):
@@ -318,7 +320,9 @@ def main():
         from cusmc_amd import sharding
         _, cnt = sharding.shard_range(N_PER_GPU, rank, world)
         Xs, outs = X[:cnt], out[:cnt]
-        s_head = timed_max(lambda: mvn.pdf_dev(Xs, outs), max(args.steps, 200), warm=50)
+        # (warm-up: the clock governor's transient, as for the headline -- 200 launches straight after an idle
+        # period run ~10 % slow, profiles/r01_calibration.txt)
+        s_head = timed_max(lambda: mvn.pdf_dev(Xs, outs), max(args.steps, 200), warm=600)
         strong = {"headline_1e6x64": {"total_particles": N_PER_GPU, "particles_per_gpu": cnt, "evals_per_s": N_PER_GPU / s_head,
                                       "us_per_launch": s_head * 1e6,
                                       "hbm_frac_per_gpu": cnt * ALGO_BYTES_PER_EVAL / s_head / 1e9 / HBM_PEAK_GBS}}
@@ -336,6 +340,8 @@ def main():
         d256.close()
         del X5, out5
     except Exception as exc:  # noqa: BLE001
+        if world > 1:
+            raise  # a rank that skips ahead would pair its next collective with its peers' current one
         strong = {"error": repr(exc), "partial": strong}
 
     # One bootstrap-filter time step with the particles sharded (BASELINE configs[2]: 1e6 particles in all):
@@ -365,6 +371,8 @@ def main():
             obs.close()
             obs2.close()
     except Exception as exc:  # noqa: BLE001
+        if world > 1:
+            raise
         filt = {"error": repr(exc), "partial": filt}
 
     # The CPU leg is the only place bench.py touches oracle/: it times the reference-faithful port

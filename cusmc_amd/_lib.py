@@ -23,6 +23,7 @@ SYMBOLS = [
     ("cusmc_version", C.c_char_p, []),
     ("cusmc_last_error", C.c_char_p, []),
     ("cusmc_device_count", _i, []),
+    ("cusmc_stream_key", _u64, [_u64, _u64]),
     ("cusmc_ctx_create", _i, [_i, _pp]),
     ("cusmc_ctx_destroy", _i, [_vp]),
     ("cusmc_ctx_set_stream", _i, [_vp, _vp]),

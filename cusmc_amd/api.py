@@ -114,6 +114,15 @@ def _next_stream():
     return _rng["seed"], _rng["calls"]
 
 
+def _next_key():
+    """The Philox key of the next R-level call: cusmc_stream_key(session seed, call counter).  Every
+    unseeded MVN() / MVT() / metropolis_hastings() / run() gets a key of its own, so repeated calls are
+    independent replications (the reference reseeds from std::random_device per call) and no two calls
+    share counters, while set_seed() / CUSMC_SEED reproduce the whole sequence of calls."""
+    seed, call = _next_stream()
+    return int(_lib.lib().cusmc_stream_key(seed, call))
+
+
 def eigenSolver(sigma):
     """eigenSolver(I_sol, sigma) -- src/linear_algebra.cpp:10-23: Q = V sqrt(Lambda)."""
     sigma = _f64(sigma)
@@ -217,7 +226,7 @@ class _Distribution:
         X = _f64(X)
         if X.ndim != 2 or X.shape[1] != self.d:
             raise ValueError("X must be N x %d" % self.d)
-        Fm = None if F is None else _f64(F)
+        Fm = None if F is None else self._square(F, "F")
         out = np.empty(X.shape[0])
         check(_lib.lib().cusmc_dist_pdf_host(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(Fm),
                                              OUT_LOG if log else OUT_DENSITY, _ptr(out)))
@@ -228,7 +237,7 @@ class _Distribution:
         X, y = _f64(X), _f64(y).reshape(-1)
         if X.ndim != 2 or X.shape[1] != self.d or y.shape[0] != self.d:
             raise ValueError("X must be N x %d and y of length %d" % (self.d, self.d))
-        Fm = None if F is None else _f64(F)
+        Fm = None if F is None else self._square(F, "F")
         out = np.empty(X.shape[0])
         check(_lib.lib().cusmc_dist_reweight_host(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(y),
                                                   _ptr(Fm), OUT_LOG if log else OUT_DENSITY,
@@ -236,18 +245,28 @@ class _Distribution:
         return out
 
     # -- batched interface (device-resident torch tensors) -----------------------------------
-    @staticmethod
-    def _tensor_args(X, out):
+    def _tensor_args(self, X, out):
         import torch
         if not (X.is_cuda and out.is_cuda and X.dtype == torch.float64 and out.dtype == torch.float64):
             raise ValueError("X and out must be float64 CUDA tensors")
-        if X.dim() != 2 or X.stride(1) != 1 or not out.is_contiguous() or out.numel() != X.shape[0]:
+        if X.dim() != 2 or X.shape[1] != self.d:
+            raise ValueError("X must be N x %d, got %s" % (self.d, tuple(X.shape)))
+        if X.stride(1) != 1 or not out.is_contiguous() or out.numel() != X.shape[0]:
             raise ValueError("X must be N x d with unit inner stride; out contiguous of length N")
-        return X.data_ptr(), X.shape[0], (X.stride(0) if X.shape[0] > 1 else X.shape[1]), out.data_ptr()
+        ldx = X.stride(0) if X.shape[0] > 1 else X.shape[1]
+        if ldx < self.d:
+            raise ValueError("rows of X overlap (row stride %d < d = %d)" % (ldx, self.d))
+        return X.data_ptr(), X.shape[0], ldx, out.data_ptr()
+
+    def _square(self, M, name):
+        M = _f64(M)
+        if M.shape != (self.d, self.d):
+            raise ValueError("%s must be %d x %d, got %s" % (name, self.d, self.d, M.shape))
+        return M
 
     def pdf_dev(self, X, out, F=None, log=True):
         xp, n, ldx, op = self._tensor_args(X, out)
-        Fm = None if F is None else _f64(F)
+        Fm = None if F is None else self._square(F, "F")
         check(_lib.lib().cusmc_dist_pdf_dev(self._h, C.c_void_p(xp), n, ldx, _ptr(Fm),
                                             OUT_LOG if log else OUT_DENSITY, C.c_void_p(op)))
         return out
@@ -255,7 +274,9 @@ class _Distribution:
     def reweight_dev(self, X, y, F, out, log=True):
         xp, n, ldx, op = self._tensor_args(X, out)
         y = _f64(y).reshape(-1)
-        Fm = None if F is None else _f64(F)
+        if y.shape[0] != self.d:
+            raise ValueError("y must have %d entries" % self.d)
+        Fm = None if F is None else self._square(F, "F")
         check(_lib.lib().cusmc_dist_reweight_dev(self._h, C.c_void_p(xp), n, ldx, _ptr(y), _ptr(Fm),
                                                  OUT_LOG if log else OUT_DENSITY, C.c_void_p(op)))
         return out
@@ -268,8 +289,10 @@ class _Distribution:
         (scale sqrt(3)); the default is the statistically correct N(0,1)."""
         del n_iterations
         if seed is None:
-            seed, step = _next_stream()
+            seed, step = _next_key(), 0
         Q = _f64(Q)
+        if Q.shape != (self.d, self.d):
+            raise ValueError("Q must be %d x %d" % (self.d, self.d))
         out = np.empty((count, self.d))
         check(_lib.lib().cusmc_sample_host(self.ctx._h, self._kind, C.c_float(self.nu), _ptr(self.mu),
                                            _ptr(Q), self.d, SQRT3 if compat else 1.0, seed,
@@ -307,6 +330,37 @@ class MultiVariateTStudentDistribution(_Distribution):
         return self.nu
 
 
+def _dev_matrix(t, name, d=None):
+    """float64 CUDA N x d tensor, rows contiguous and packed (the ABI's proposal / filter entry points take
+    no leading dimension: rows are d doubles apart)."""
+    import torch
+    if not (t.is_cuda and t.dtype == torch.float64 and t.dim() == 2 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous float64 CUDA tensor N x d" % name)
+    if d is not None and t.shape[1] != d:
+        raise ValueError("%s must have %d columns, got %d" % (name, d, t.shape[1]))
+    return t
+
+
+def _dev_vector(t, name, dtypes, n=None):
+    if not (t.is_cuda and t.dtype in dtypes and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous CUDA tensor of dtype %s" % (name, " / ".join(str(x) for x in dtypes)))
+    if n is not None and t.numel() != n:
+        raise ValueError("%s must have %d entries, got %d" % (name, n, t.numel()))
+    return t
+
+
+def _index_dtypes():
+    import torch
+    return (torch.int32, torch.uint32) if hasattr(torch, "uint32") else (torch.int32,)
+
+
+def _host_square(M, d, name):
+    M = _f64(M)
+    if M.shape != (d, d):
+        raise ValueError("%s must be %d x %d, got %s" % (name, d, d, M.shape))
+    return M
+
+
 class Sampler:
     """inst/include/samplers.hpp:7-18."""
 
@@ -330,7 +384,9 @@ class Sampler:
         logw = _f64(logw).reshape(-1)
         N = logw.shape[0] if N is None else int(N)
         if seed is None:
-            seed, _ = _next_stream()
+            seed = _next_key()
+        if N > logw.shape[0]:
+            raise ValueError("N = %d exceeds the %d log-weights given" % (N, logw.shape[0]))
         ctx = ctx or default_context()
         a = np.empty(N, dtype=np.uint32)
         check(_lib.lib().cusmc_metropolis_log_host(ctx._h, _ptr(logw), N, int(B), int(seed), int(t), _ptr(a)))
@@ -338,7 +394,10 @@ class Sampler:
 
     @staticmethod
     def metropolis_hastings_log_dev(logw, a, B=10, t=1, seed=0, first=0, ctx=None):
+        import torch
         ctx = ctx or default_context()
+        _dev_vector(logw, "logw", (torch.float64,))
+        _dev_vector(a, "a", _index_dtypes())
         check(_lib.lib().cusmc_metropolis_log_dev(ctx._h, C.c_void_p(logw.data_ptr()), logw.numel(), int(B),
                                                   int(seed), int(t), int(first), a.numel(),
                                                   C.c_void_p(a.data_ptr())))
@@ -348,7 +407,10 @@ class Sampler:
     def metropolis_hastings_dev(w, a, B=10, t=1, seed=0, first=0, ctx=None):
         """Device-resident: w float64 CUDA tensor (all N weights), a int32/uint32-sized CUDA
         tensor receiving the ancestors of chains [first, first + len(a))."""
+        import torch
         ctx = ctx or default_context()
+        _dev_vector(w, "w", (torch.float64,))
+        _dev_vector(a, "a", _index_dtypes())
         check(_lib.lib().cusmc_metropolis_dev(ctx._h, C.c_void_p(w.data_ptr()), w.numel(), int(B),
                                               int(seed), int(t), int(first), a.numel(),
                                               C.c_void_p(a.data_ptr())))
@@ -360,8 +422,11 @@ def propagate_dev(X_prev, a, G, Q, X_out, kind="mvn", nu=0.0, scale=1.0, seed=0,
     X_out[i] = [diag(c)] Q (scale xi) + G X_prev[a[i]] for the rows [first, first + len(X_out)).
     X_prev: N x d float64 CUDA tensor; a: int32 CUDA tensor of len(X_out) ancestors, or None."""
     ctx = ctx or default_context()
-    G, Q = _f64(G), _f64(Q)
-    d = X_prev.shape[1]
+    d = _dev_matrix(X_prev, "X_prev").shape[1]
+    _dev_matrix(X_out, "X_out", d)
+    if a is not None:
+        _dev_vector(a, "a", _index_dtypes(), X_out.shape[0])
+    G, Q = _host_square(G, d, "G"), _host_square(Q, d, "Q")
     check(_lib.lib().cusmc_propagate_dev(ctx._h, _MVT if kind == "mvt" else _MVN, C.c_float(nu),
                                          C.c_void_p(X_prev.data_ptr()),
                                          None if a is None else C.c_void_p(a.data_ptr()), X_prev.shape[0], d,
@@ -376,8 +441,17 @@ def pf_step_dev(obs, w_prev, X_prev, G, Q, y, F, a_out, X_out, w_out, kind="mvn"
     resample over w_prev -> propagate -> reweight against the observation distribution `obs`
     (pdf_{0,V}: its own mu is not used), for the rows [first, first + len(a_out)).  One launch for
     d <= 8, the three separate kernels otherwise; same numbers either way."""
-    G, Q, y = _f64(G), _f64(Q), _f64(y).reshape(-1)
-    Fm = None if F is None else _f64(F)
+    import torch
+    d = obs.d
+    _dev_matrix(X_prev, "X_prev", d)
+    _dev_matrix(X_out, "X_out", d)
+    _dev_vector(w_prev, "w_prev", (torch.float64,), X_prev.shape[0])
+    _dev_vector(a_out, "a_out", _index_dtypes(), X_out.shape[0])
+    _dev_vector(w_out, "w_out", (torch.float64,), X_out.shape[0])
+    G, Q, y = _host_square(G, d, "G"), _host_square(Q, d, "Q"), _f64(y).reshape(-1)
+    if y.shape[0] != d:
+        raise ValueError("y must have %d entries" % d)
+    Fm = None if F is None else _host_square(F, d, "F")
     check(_lib.lib().cusmc_pf_step_dev(obs._h, _MVT if kind == "mvt" else _MVN, C.c_float(nu),
                                        C.c_void_p(w_prev.data_ptr()), C.c_void_p(X_prev.data_ptr()),
                                        X_prev.shape[0], _ptr(G), _ptr(Q), _ptr(y), _ptr(Fm), int(B), float(scale),
@@ -390,7 +464,10 @@ def pf_step_dev(obs, w_prev, X_prev, G, Q, y, F, a_out, X_out, w_out, kind="mvn"
 def initialize_dev(m0, Q, X_out, kind="mvn", nu=0.0, scale=1.0, seed=0, first=0, ctx=None):
     """initialize() draws on a device-resident tensor (src/mcmc.cpp:44-88)."""
     ctx = ctx or default_context()
-    m0, Q = _f64(m0), _f64(Q)
+    m0 = _f64(m0).reshape(-1)
+    d = m0.shape[0]
+    _dev_matrix(X_out, "X_out", d)
+    Q = _host_square(Q, d, "Q")
     check(_lib.lib().cusmc_initialize_dev(ctx._h, _MVT if kind == "mvt" else _MVN, C.c_float(nu), _ptr(m0),
                                           _ptr(Q), m0.shape[0], float(scale), int(seed), int(first),
                                           X_out.shape[0], C.c_void_p(X_out.data_ptr())))
@@ -488,9 +565,8 @@ def MVT(mu, sigma, nu, compat=False):
 def metropolis_hastings(w, N, B):
     """VectorXd metropolis_hastings(w, N, B) -- src/samplers.rcpp.cpp:35-55: t = 1, returns the
     N ancestors as DOUBLES, 0-based, like the reference."""
-    seed, call = _next_stream()
-    # the call counter takes the place of t so that successive R-level calls are independent
-    return Sampler.metropolis_hastings(w, N, t=call, B=B, seed=seed).astype(np.float64)
+    # t = 1 as the reference's export passes it (src/samplers.rcpp.cpp:43); a fresh key per call
+    return Sampler.metropolis_hastings(w, N, t=1, B=B, seed=_next_key()).astype(np.float64)
 
 
 def run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p=0, B=10,
@@ -508,7 +584,12 @@ def run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p=0
     Yt = np.ascontiguousarray(Y.T)
     m0, C0, F, G, V, W = (_f64(a) for a in (m0, C0, F, G, V, W))
     if seed is None:
-        seed, _ = _next_stream()
+        seed = _next_key()
+    for name, m in (("C0", C0), ("F", F), ("G", G), ("V", V), ("W", W)):
+        if m.shape != (d, d):
+            raise ValueError("%s must be %d x %d, got %s" % (name, d, d, m.shape))
+    if m0.reshape(-1).shape[0] != d:
+        raise ValueError("m0 must have %d entries" % d)
     ctx = default_context()
     X = np.empty((T, N, d))
     w = np.empty((T, N))

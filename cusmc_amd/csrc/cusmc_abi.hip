@@ -4,12 +4,16 @@
 // call without a usable device fails with CUSMC_ENODEVICE / CUSMC_EHIP.
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <atomic>
@@ -353,7 +357,21 @@ int plan_affine(cusmc_dist *dist, const double *y, const double *F)
 
 // ---- library / context ----------------------------------------------------------------------
 
-CUSMC_EXPORT const char *cusmc_version(void) { return "cusmc-hip 0.1 (gfx950)"; }
+CUSMC_EXPORT const char *cusmc_version(void) { return "cusmc-hip 0.2 (gfx950)"; }
+
+// One independent Philox key per R-level call: the (call + 1)-th output of SplitMix64 seeded with
+// `seed`.  The R-level draw / resample / run() entry points have no seed argument (the reference
+// reseeds from std::random_device on every call: src/samplers.cpp:10-11, src/statistics.cc.cpp:231-232);
+// the host layers (cusmc_amd/api.py, rcpp/src/glue.hpp) keep a session seed and a call counter and hand
+// cusmc_stream_key(seed, counter) to the entry points below as their 64-bit seed, so that successive
+// calls never share a (key, counter) pair while a seeded session stays reproducible.
+CUSMC_EXPORT uint64_t cusmc_stream_key(uint64_t seed, uint64_t call)
+{
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (call + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
 CUSMC_EXPORT const char *cusmc_last_error(void) { return g_last_error.c_str(); }
 
 CUSMC_EXPORT int cusmc_device_count(void)
@@ -363,10 +381,29 @@ CUSMC_EXPORT int cusmc_device_count(void)
   return n;
 }
 
+namespace {
+// CUSMC_TRACE_TERMINATE=1: print the call stack of whatever reaches std::terminate (diagnostic for
+// aborts at process exit: whose destructor threw).  Off by default.
+void trace_terminate()
+{
+  static const char msg[] = "[cusmc] std::terminate reached; call stack:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  void *frames[64];
+  const int n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, 2);
+  abort();
+}
+}  // namespace
+
 CUSMC_EXPORT int cusmc_ctx_create(int device, cusmc_ctx **out)
 {
   if (!out) return fail(CUSMC_EINVAL, "null output pointer");
   *out = nullptr;
+  static const bool traced = [] {
+    if (getenv("CUSMC_TRACE_TERMINATE")) std::set_terminate(trace_terminate);
+    return true;
+  }();
+  (void)traced;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
     return fail(CUSMC_ENODEVICE, "no HIP device visible: libcusmc_hip has no CPU fallback");
@@ -754,7 +791,12 @@ CUSMC_EXPORT int cusmc_propagate_dev(cusmc_ctx *ctx, int kind, float nu, const d
 {
   if (!ctx) return fail(CUSMC_EINVAL, "null context");
   if (!G || !X_prev_dev) return fail(CUSMC_EINVAL, "null G or X_prev");
-  if ((uint64_t)first + count > N) return fail(CUSMC_EINVAL, "shard [%u, %u) exceeds N = %u", first, first + count, N);
+  // a == NULL reads X_prev[i] for the global i itself; with an ancestor array the rows of X_prev are
+  // named by a[] alone and [first, first+count) only keys the draws (a sharded caller passes the
+  // rows it fetched for its own particles: N = count, a = 0 .. count-1, first = its global offset)
+  if (!a_dev && (uint64_t)first + count > N)
+    return fail(CUSMC_EINVAL, "shard [%u, %u) exceeds N = %u", first, first + count, N);
+  if ((uint64_t)first + count > 0xffffffffull) return fail(CUSMC_EINVAL, "first + count exceeds 2^32");
   return draws(ctx, kind, nu, X_prev_dev, a_dev, G, Q, nullptr, d, scale, seed, step, 2u, first, count, X_out_dev);
 }
 

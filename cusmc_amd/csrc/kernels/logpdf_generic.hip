@@ -148,7 +148,7 @@ static hipError_t launch_t(const double *X, int64_t N, int64_t ldx, int d, bool 
 {
   const size_t lds_bytes = (size_t)T * (d | 1) * sizeof(double);
   auto kern = logpdf_generic_kernel<T>;
-  static std::atomic<unsigned long long> lds_configured{0};
+  static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
   const long num_tiles = (N + T - 1) / T;
   int per_cu = (int)((160 * 1024) / lds_bytes);

@@ -44,7 +44,7 @@ static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, int d, cons
   const size_t lds_bytes = (size_t)(32 * NB + 4 + NFRAG * 64) * sizeof(double);  // (the factor passes through LDS in every variant)
   const long num_tiles = (N + 15) / 16;
   auto kern = logpdf_mfma_kernel<NB, CENTRED, SHIFT, 0, EPI, PAD>;
-  static std::atomic<unsigned long long> lds_configured{0};
+  static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
   // one persistent workgroup per CU (its waves share the round counter), fewer when there is
   // less work than that

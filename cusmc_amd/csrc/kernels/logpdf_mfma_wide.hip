@@ -426,7 +426,7 @@ static hipError_t launch_wide(const double *X, int64_t N, int64_t ldx, int d, co
 {
   auto kern = logpdf_mfma_wide_kernel<NB, CENTRED, SHIFT, 0, PAD>;
   const size_t lds_bytes = wide_lds_bytes(NB);
-  static std::atomic<unsigned long long> lds_configured{0};
+  static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
   constexpr int GP = wide_gp(NB);
   const long num_groups = (N + GP - 1) / GP;

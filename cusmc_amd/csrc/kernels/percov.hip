@@ -191,7 +191,7 @@ static hipError_t launch_chol(const double *S, int64_t N, double *L, double *log
                               hipStream_t stream)
 {
   const size_t lds = percov_lds_bytes<D>(true);
-  static std::atomic<unsigned long long> lds_configured{0};
+  static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(cholesky_batched_kernel<D>), lds, lds_configured); e != hipSuccess) return e;
   hipLaunchKernelGGL(cholesky_batched_kernel<D>, dim3((unsigned)percov_blocks(N, num_cus)), dim3(kPercovLanes), lds,
                      stream, S, (long)N, L, logdet, info);
@@ -203,7 +203,7 @@ static hipError_t launch_lp(const double *X, int64_t N, int64_t ldx, const doubl
                             const Epilogue &ep, double *out, int *info, int num_cus, hipStream_t stream)
 {
   const size_t lds = percov_lds_bytes<D>(false);
-  static std::atomic<unsigned long long> lds_configured{0};
+  static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(logpdf_percov_kernel<D>), lds, lds_configured); e != hipSuccess) return e;
   hipLaunchKernelGGL(logpdf_percov_kernel<D>, dim3((unsigned)percov_blocks(N, num_cus)), dim3(kPercovLanes), lds,
                      stream, X, (long)N, (long)ldx, mu, (long)ldmu, S, ep, out, info);

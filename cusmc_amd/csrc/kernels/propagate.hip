@@ -277,7 +277,7 @@ static hipError_t launch_t(int kind, float nu, const double *X_prev, const uint3
 {
   const size_t lds_bytes = (size_t)2 * T * (d | 1) * sizeof(double);
   auto kern = propagate_kernel<T>;
-  static std::atomic<unsigned long long> lds_configured{0};
+  static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
   const long num_tiles = ((long)count + T - 1) / T;
   int per_cu = (int)((160 * 1024) / lds_bytes);

@@ -228,7 +228,7 @@ static hipError_t launch_pm(float nu, const double *X_prev, const uint32_t *a, c
   constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0, DIAG_G = MODE == 4;
   const size_t lds_bytes = (size_t)((HAS_Q ? NFRAG * 64 : 0) + (HAS_G ? NFRAG * 64 : (HAS_M0 || DIAG_G ? 16 * NB : 0)) + 2) * sizeof(double);
   auto kern = propagate_mfma_kernel<NB, MVT, MODE, PAD>;
-  static std::atomic<unsigned long long> lds_configured{0};
+  static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
   const long num_tiles = ((long)count + 15) / 16;
   long blocks = num_cus;

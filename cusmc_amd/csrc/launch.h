@@ -8,19 +8,28 @@
 
 namespace cusmc {
 
-// Raises a kernel's dynamic-LDS limit above the default 64 KB, once per (kernel instantiation, device):
-// `done` is the instantiation's own bit mask of devices already configured (a context may live on any
-// device of the process, and the attribute is per device).
-inline hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<unsigned long long> &done)
+// Raises a kernel's dynamic-LDS limit above the default 64 KB, per (kernel instantiation, device): `cfg` is
+// the instantiation's own record of the byte count configured on each device (a context may live on any
+// device of the process, and the attribute is per device).  Kernels that size their LDS from d at run
+// time come back with a larger request later (d = 130 needs 67 KB, d = 250 128 KB): the attribute is
+// raised again whenever the request exceeds what was configured -- a bare "configured" bit would let
+// the second launch fail with hipErrorInvalidValue.
+struct LdsConfig {
+  std::atomic<unsigned> bytes[64] = {};
+};
+inline hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes, LdsConfig &cfg)
 {
   if (bytes <= 64 * 1024) return hipSuccess;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
-  if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && cfg.bytes[dev].load(std::memory_order_relaxed) >= bytes) return hipSuccess;
   e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+  if (e == hipSuccess && tracked) {
+    unsigned cur = cfg.bytes[dev].load(std::memory_order_relaxed);
+    while (cur < bytes && !cfg.bytes[dev].compare_exchange_weak(cur, (unsigned)bytes, std::memory_order_relaxed)) {}
+  }
   return e;
 }
 

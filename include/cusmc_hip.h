@@ -67,6 +67,14 @@ const char *cusmc_last_error(void);
 /* Number of visible HIP devices (0 when none; never fails). */
 int cusmc_device_count(void);
 
+/* Key of the `call`-th R-level call of a session seeded with `seed` (SplitMix64 output call + 1).  The
+ * reference's R-level MVN() / MVT() / metropolis_hastings() / run() take no seed and reseed from
+ * std::random_device on every call (src/samplers.cpp:10-11, src/statistics.cc.cpp:231-232,361-362);
+ * the host layers keep (seed, call counter) and pass this key as the `seed` of the entry points
+ * below, so that no two calls of a session share Philox counters.  Pure host function; returns the
+ * key, not a status. */
+uint64_t cusmc_stream_key(uint64_t seed, uint64_t call);
+
 /* device < 0: keep the calling thread's current device.  The reference has no context: it
  * uses device 0 / the default stream implicitly and cudaDeviceReset()s after each call
  * (src/mvn_dist.cu.cpp:788). */
@@ -140,8 +148,9 @@ int cusmc_metropolis_log_host(cusmc_ctx *ctx, const double *logw, uint32_t N, ui
  * src/linear_algebra.cpp:10-23, or cusmc_eigen_sqrt below).  scale = 1 draws from N(mu, QQ^T);
  * scale = sqrt(3) reproduces the distribution of the reference's CPU transform
  * (src/statistics.cc.cpp:245-256).  a_dev == NULL means a[i] = i.
- * Rows [first, first+count) of the output are produced (X_out_dev has `count` rows); X_prev
- * has N rows. */
+ * Rows [first, first+count) of the output are produced (X_out_dev has `count` rows) and key the
+ * draws; X_prev has N rows, named by a[] (values < N) -- or, for a_dev == NULL, by i itself, in
+ * which case first + count <= N is required. */
 int cusmc_propagate_dev(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev,
                         const uint32_t *a_dev, uint32_t N, int d, const double *G,
                         const double *Q, double scale, uint64_t seed, uint32_t step,

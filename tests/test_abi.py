@@ -117,3 +117,28 @@ def test_writeOutput_layout(tmp_path):
     writeOutput(y, w, X, N, d, T, p, directory=str(tmp_path))
     assert open(tmp_path / "y_t.csv").read().splitlines() == ["y", "0,1,", "2,3,", "4,5,"]
     assert open(tmp_path / "x_t_N1.csv").read().splitlines() == ["w,x", "0,2,3", "0.4,10,11", "0.8,18,19"]
+
+
+def test_stream_key_is_splitmix64():
+    """cusmc_stream_key(seed, call) = output call+1 of SplitMix64(seed): the published test vector for
+    seed 0 (Vigna's splitmix64.c), and distinct keys across calls and seeds."""
+    from cusmc_amd import _lib
+    k = _lib.lib().cusmc_stream_key
+    assert [k(0, c) for c in range(3)] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+    keys = {k(s, c) for s in (0, 1, 2 ** 63, 2 ** 64 - 1) for c in range(1000)}
+    assert len(keys) == 4000
+
+
+def test_device_wrappers_validate_before_the_abi():
+    """the device-tensor wrappers must refuse wrong dtypes / shapes / strides with a
+    ValueError instead of handing raw pointers to the kernels (CPU tensors stand in here: the
+    checks run before any pointer is taken)."""
+    import torch
+    from cusmc_amd import api
+    x = torch.zeros(8, 4, dtype=torch.float64)
+    a = torch.zeros(8, dtype=torch.int32)
+    for call in (lambda: api.propagate_dev(x, a, np.eye(4), np.eye(4), x.clone(), ctx=object()),
+                 lambda: api.initialize_dev(np.zeros(4), np.eye(4), x, ctx=object()),
+                 lambda: api.Sampler.metropolis_hastings_dev(x[:, 0], a, ctx=object())):
+        with pytest.raises(ValueError):
+            call()

@@ -633,6 +633,88 @@ def test_R_level_draws(cs):
     assert not np.array_equal(cs.MVN([0.0, 0.0], np.eye(2)), x)   # successive calls differ
 
 
+def test_unseeded_calls_are_independent_and_a_seed_reproduces_them(cs):
+    """every unseeded R-level call draws a Philox key of its own (cusmc_stream_key(session
+    seed, call counter)) -- two run() calls in a row are different replications, as with the
+    reference's per-call std::random_device -- and set_seed(s) reproduces the whole sequence."""
+    I = np.eye(2)
+    Y = np.cumsum(0.1 * np.random.default_rng(1).standard_normal((2, 5)), axis=1)
+    args = (300, 2, 5, Y, np.zeros(2), I, I, I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn")
+
+    def session():
+        cs.set_seed(77)
+        r1, r2 = cs.run(*args), cs.run(*args)
+        a1 = cs.metropolis_hastings(np.arange(1.0, 101.0), 100, 10)
+        a2 = cs.metropolis_hastings(np.arange(1.0, 101.0), 100, 10)
+        l1 = cs.Sampler.metropolis_hastings_log(np.log(np.arange(1.0, 101.0)))
+        l2 = cs.Sampler.metropolis_hastings_log(np.log(np.arange(1.0, 101.0)))
+        t1, t2 = cs.MVT(np.zeros(3), np.eye(3), 3.0), cs.MVT(np.zeros(3), np.eye(3), 3.0)
+        return r1, r2, a1, a2, l1, l2, t1, t2
+
+    s1, s2 = session(), session()
+    r1, r2, a1, a2, l1, l2, t1, t2 = s1
+    assert not np.array_equal(r1["posterior_x"], r2["posterior_x"]) and not np.array_equal(r1["weights"], r2["weights"])
+    assert not np.array_equal(a1, a2) and not np.array_equal(l1, l2) and not np.array_equal(t1, t2)
+    for u, v in zip(s1, s2):   # the same seed gives the same sequence of calls
+        if isinstance(u, dict):
+            assert np.array_equal(u["posterior_x"], v["posterior_x"]) and np.array_equal(u["weights"], v["weights"])
+        else:
+            assert np.array_equal(u, v)
+    cs.set_seed(2024)
+
+
+def test_device_wrappers_reject_bad_tensors(cs):
+    """shape / dtype / stride mistakes are ValueErrors, not out-of-bounds reads."""
+    import torch
+    from cusmc_amd import api
+    D = cs.MultiVariateNormalDistribution(np.zeros(4), np.eye(4))
+    X = torch.zeros(64, 6, dtype=torch.float64, device="cuda")
+    out = torch.zeros(64, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        D.pdf_dev(X, out)                                    # wider than d: no silent first-d-columns
+    with pytest.raises(ValueError):
+        D.pdf_dev(X[:, :4].float(), out)                     # dtype
+    with pytest.raises(ValueError):
+        D.pdf_dev(X[:, :4], out, F=np.eye(3))                # F not d x d
+    D.pdf_dev(X[:, :4], out)                                 # a strided view with ldx = 6 is fine
+    Xp = torch.zeros(64, 4, dtype=torch.float64, device="cuda")
+    a = torch.zeros(64, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        api.propagate_dev(Xp[:, :2], a, np.eye(2), np.eye(2), Xp[:, :2].contiguous())   # strided X_prev
+    with pytest.raises(ValueError):
+        api.propagate_dev(Xp, a[:10], np.eye(4), np.eye(4), Xp.clone())                 # len(a) != len(X_out)
+    with pytest.raises(ValueError):
+        api.propagate_dev(Xp, a, np.eye(3), np.eye(4), Xp.clone())                      # G not d x d
+    with pytest.raises(ValueError):
+        api.propagate_dev(Xp, a.long(), np.eye(4), np.eye(4), Xp.clone())               # int64 ancestors
+    w = torch.ones(64, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        api.pf_step_dev(D, w[:10], Xp, np.eye(4), np.eye(4), np.zeros(4), None, a, Xp.clone(), w.clone())
+    with pytest.raises(ValueError):
+        cs.Sampler.metropolis_hastings_dev(w.float(), a)
+    D.close()
+
+
+def test_generic_fallback_raises_its_lds_limit_again(cs):
+    """the staged generic kernel sizes its dynamic LDS from d; a first call above
+    64 KB (d = 130) must not pin the limit for a later, larger d (250).  Reached through a row stride
+    >= 2^24 doubles, which only the generic kernel serves."""
+    import torch
+    rng = np.random.default_rng(12)
+    big = torch.zeros(3, 2 ** 24, dtype=torch.float64, device="cuda")
+    out = torch.empty(3, dtype=torch.float64, device="cuda")
+    for d in (130, 250):
+        S = spd(rng, d)
+        Xh = rng.standard_normal((3, d))
+        big[:, :d] = torch.from_numpy(Xh).cuda()
+        D = cs.MultiVariateNormalDistribution(np.zeros(d), S)
+        D.pdf_dev(big[:, :d], out)
+        want = D.pdf_batch(Xh)
+        assert rel_err(out.cpu().numpy(), want) < 1e-9
+        D.close()
+    del big
+
+
 def test_filter_against_golden(cs, golden):
     """d = 2, T = 10, N = 64 on the reference's example observations (data_raw/y_t.csv rows)."""
     I = np.eye(2)
