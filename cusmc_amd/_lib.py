@@ -54,6 +54,8 @@ SYMBOLS = [
                                _u32, _vp, _vp, _vp, _i]),
     ("cusmc_pf_run_host", _i, [_vp, _vp, _u32, _i, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _f,
                                C.c_char_p, C.c_char_p, _u32, _d, _u64, _vp, _vp, _vp]),
+    ("cusmc_pf_run_multi_host", _i, [C.POINTER(_i), _i, _vp, _u32, _i, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _f,
+                                     C.c_char_p, C.c_char_p, _u32, _d, _u64, _vp, _vp, _vp]),
 ]
 
 _lib = None

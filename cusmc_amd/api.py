@@ -570,11 +570,14 @@ def metropolis_hastings(w, N, B):
 
 
 def run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p=0, B=10,
-        compat=False, seed=None, write_csv=False, return_ancestors=False):
+        compat=False, seed=None, write_csv=False, return_ancestors=False, devices=None):
     """List run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p)
     -- src/run.rcpp.cpp:58-126.  Returns {"weights": T x N, "posterior_x": T x N x d}.
     df reaches the filter as df (the reference passes it in the wrong slot: SURVEY.md F8).
-    B = 10 is the reference's hard-coded value (src/mcmc.cpp:291)."""
+    B = 10 is the reference's hard-coded value (src/mcmc.cpp:291).
+    devices = [0, 1, ...] shards the particles over those GPUs below the C ABI
+    (cusmc_pf_run_multi_host; same numbers as one GPU); the environment variable CUSMC_DEVICES="0,1,..."
+    does the same for callers that cannot pass the argument (the R package)."""
     N, d, T = int(N), int(d), int(timeSteps)
     if not 0 <= int(p) < N:
         raise ValueError("p = %d must satisfy 0 <= p < N" % p)  # assert(p < N): run.rcpp.cpp:64
@@ -594,10 +597,14 @@ def run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p=0
     X = np.empty((T, N, d))
     w = np.empty((T, N))
     a = np.empty((T, N), dtype=np.uint32) if return_ancestors else None  # (not copied back unless asked for)
-    check(_lib.lib().cusmc_pf_run_host(ctx._h, _ptr(Yt), N, d, T, _ptr(m0), _ptr(C0), _ptr(F), _ptr(G),
-                                       _ptr(V), _ptr(W), C.c_float(df), str(resampler).encode(),
-                                       str(distribution).encode(), int(B),
-                                       SQRT3 if compat else 1.0, int(seed), _ptr(X), _ptr(w), _ptr(a)))
+    tail = (_ptr(Yt), N, d, T, _ptr(m0), _ptr(C0), _ptr(F), _ptr(G), _ptr(V), _ptr(W), C.c_float(df),
+            str(resampler).encode(), str(distribution).encode(), int(B), SQRT3 if compat else 1.0, int(seed),
+            _ptr(X), _ptr(w), _ptr(a))
+    if devices is not None:
+        devs = (C.c_int * len(devices))(*[int(v) for v in devices])
+        check(_lib.lib().cusmc_pf_run_multi_host(devs, len(devices), *tail))
+    else:
+        check(_lib.lib().cusmc_pf_run_host(ctx._h, *tail))
     if write_csv:
         from .io import writeOutput
         writeOutput(Yt, w, X, N, d, T, int(p))

@@ -17,6 +17,8 @@
 #include <new>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -1074,6 +1076,22 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
                                    uint32_t *a_out)
 {
   if (int rc = activate(ctx)) return rc;
+  // CUSMC_DEVICES="0,1,2,3": the same call shards the particles over those GPUs, so
+  // that callers bound to this entry point -- the R package's run() -- use the node without a new argument
+  if (const char *env = getenv("CUSMC_DEVICES")) {
+    std::vector<int> devs;
+    for (const char *c = env; *c;) {
+      char *end = nullptr;
+      const long v = strtol(c, &end, 10);
+      if (end == c) return fail(CUSMC_EINVAL, "CUSMC_DEVICES='%s' is not a comma-separated list of device numbers", env);
+      devs.push_back((int)v);
+      c = *end == ',' ? end + 1 : end;
+      if (*end && *end != ',') return fail(CUSMC_EINVAL, "CUSMC_DEVICES='%s' is not a comma-separated list of device numbers", env);
+    }
+    if (devs.size() > 1)
+      return cusmc_pf_run_multi_host(devs.data(), (int)devs.size(), Y, N, d, T, m0, C0, F, G, V, W, df, resampler,
+                                     distribution, B, scale, seed, X_out, w_out, a_out);
+  }
   // validate the option strings BEFORE any work: the reference default-constructs an empty
   // std::function for an unknown key and throws bad_function_call mid-run (mcmc.cpp:269-272)
   if (!resampler || strcmp(resampler, "metropolis") != 0)
@@ -1262,4 +1280,236 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   const int done = cleanup(CUSMC_OK);
   phase("device memory released");
   return done;
+}
+
+// ---- the filter on several GPUs ---------------------------------------------------------------------
+//
+// MCMC()'s time loop (src/mcmc.cpp:292-308) with the particles sharded contiguously over `ndev` devices of
+// one node, one host thread and one context per device -- the exact algorithm, not an island filter, and
+// bit for bit the single-device result, because every draw is keyed by the GLOBAL particle index.  Per
+// step and device:
+//     resample its own chains over the full weight vector w_{t-1}        (cusmc_metropolis_dev)
+//     fetch the rows x_{t-1}[a_i] its ancestors name from their owners   (kernels/gather.hip: peer reads)
+//     propagate and reweight its own particles                           (the single-device kernels)
+//     copy its w_t shard into every device's copy of w_t                 (hipMemcpyPeerAsync)
+// then all threads meet at a barrier.  Bytes into a device per step: 8 (N - N/R) of weights and at most
+// 8 d N/R of rows (the ancestors that live elsewhere) -- never the whole of x_{t-1}.  The reference has no
+// counterpart: its loop runs on one host (zero collective call sites).
+namespace {
+
+struct ThreadBarrier {
+  std::mutex m;
+  std::condition_variable cv;
+  int n, waiting = 0;
+  unsigned gen = 0;
+  explicit ThreadBarrier(int n_) : n(n_) {}
+  void wait()
+  {
+    std::unique_lock<std::mutex> lock(m);
+    const unsigned g = gen;
+    if (++waiting == n) {
+      waiting = 0;
+      ++gen;
+      cv.notify_all();
+    } else {
+      cv.wait(lock, [&] { return g != gen; });
+    }
+  }
+};
+
+struct FilterShard {
+  int device = 0;
+  uint32_t first = 0, count = 0;
+  cusmc_ctx *ctx = nullptr;
+  cusmc_dist *obs = nullptr;
+  hipStream_t stream = nullptr;
+  DevBuf X, w, a, wfull, anc, ident;  // history [T][count][d], [T][count], [T][count]; 2 x N weights; count x d; count
+  int rc = CUSMC_OK;
+  std::string error;
+};
+
+}  // namespace
+
+CUSMC_EXPORT int cusmc_pf_run_multi_host(const int *devices, int ndev, const double *Y, uint32_t N, int d,
+                                         uint32_t T, const double *m0, const double *C0, const double *F,
+                                         const double *G, const double *V, const double *W, float df,
+                                         const char *resampler, const char *distribution, uint32_t B,
+                                         double scale, uint64_t seed, double *X_out, double *w_out,
+                                         uint32_t *a_out)
+{
+  if (!devices || ndev < 1) return fail(CUSMC_EINVAL, "empty device list");
+  if (ndev > cusmc::kMaxShards) return fail(CUSMC_ERANGE, "%d devices exceed the %d supported", ndev, cusmc::kMaxShards);
+  if (!resampler || strcmp(resampler, "metropolis") != 0)
+    return fail(CUSMC_EINVAL, "unknown resampler '%s' (known: metropolis)", resampler ? resampler : "(null)");
+  int kind;
+  if (distribution && !strcmp(distribution, "mvn")) kind = CUSMC_MVN;
+  else if (distribution && !strcmp(distribution, "mvt")) kind = CUSMC_MVT;
+  else return fail(CUSMC_EINVAL, "unknown distribution '%s' (known: mvn, mvt)", distribution ? distribution : "(null)");
+  if (!Y || !m0 || !C0 || !F || !G || !V || !W) return fail(CUSMC_EINVAL, "null model argument");
+  if (N == 0 || T == 0 || d < 1) return fail(CUSMC_EINVAL, "N, T and d must be positive");
+  if ((uint32_t)ndev > N) return fail(CUSMC_EINVAL, "%d devices for N = %u particles", ndev, N);
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible == 0)
+    return fail(CUSMC_ENODEVICE, "no HIP device visible: libcusmc_hip has no CPU fallback");
+  for (int r = 0; r < ndev; ++r)
+    if (devices[r] < 0 || devices[r] >= visible)
+      return fail(CUSMC_EINVAL, "device %d out of range (%d visible)", devices[r], visible);
+
+  if (ndev == 1) {
+    cusmc_ctx *ctx = nullptr;
+    if (int rc = cusmc_ctx_create(devices[0], &ctx)) return rc;
+    // (no recursion through CUSMC_DEVICES: one device runs the plain loop)
+    const char *env = getenv("CUSMC_DEVICES");
+    std::string saved = env ? env : "";
+    if (env) unsetenv("CUSMC_DEVICES");
+    const int rc = cusmc_pf_run_host(ctx, Y, N, d, T, m0, C0, F, G, V, W, df, resampler, distribution, B, scale, seed,
+                                     X_out, w_out, a_out);
+    if (env) setenv("CUSMC_DEVICES", saved.c_str(), 1);
+    cusmc_ctx_destroy(ctx);
+    return rc;
+  }
+
+  // peers must be able to read each other's memory (several shards may also share one device: the
+  // rehearsal of this path on a one-GPU box)
+  for (int i = 0; i < ndev; ++i)
+    for (int j = 0; j < ndev; ++j) {
+      if (devices[i] == devices[j]) continue;
+      int can = 0;
+      HIP_TRY(hipDeviceCanAccessPeer(&can, devices[i], devices[j]));
+      if (!can) return fail(CUSMC_EHIP, "device %d cannot access device %d's memory", devices[i], devices[j]);
+      HIP_TRY(hipSetDevice(devices[i]));
+      const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+        return fail(CUSMC_EHIP, "%s enabling peer access %d -> %d", hipGetErrorString(e), devices[i], devices[j]);
+      (void)hipGetLastError();
+    }
+
+  std::vector<double> Q0((size_t)d * d), Qw((size_t)d * d);
+  cusmc::la::eigen_sqrt(C0, d, Q0.data());
+  cusmc::la::eigen_sqrt(W, d, Qw.data());
+
+  std::vector<FilterShard> sh(ndev);
+  {
+    const uint32_t base = N / (uint32_t)ndev, extra = N % (uint32_t)ndev;
+    uint32_t first = 0;
+    for (int r = 0; r < ndev; ++r) {
+      sh[r].device = devices[r];
+      sh[r].first = first;
+      sh[r].count = base + ((uint32_t)r < extra ? 1u : 0u);
+      first += sh[r].count;
+    }
+  }
+  ThreadBarrier barrier(ndev);
+  std::atomic<bool> abort_run{false};
+
+  auto worker = [&](int r) {
+    FilterShard &me = sh[r];
+    const size_t rows = me.count, slice = rows * d;
+    auto guard = [&](int rc) {  // records the first failure of this thread; the loop keeps meeting the barriers
+      if (rc && !me.rc) {
+        me.rc = rc;
+        me.error = g_last_error;
+        abort_run.store(true);
+      }
+      return rc;
+    };
+    auto hip = [&](hipError_t e, const char *what) {
+      return e == hipSuccess ? CUSMC_OK : fail(CUSMC_EHIP, "%s: %s (device %d)", what, hipGetErrorString(e), me.device);
+    };
+    // ---- set-up
+    int rc = cusmc_ctx_create(me.device, &me.ctx);
+    if (!rc) rc = hip(hipStreamCreateWithFlags(&me.stream, hipStreamNonBlocking), "stream");
+    if (!rc) me.ctx->stream = me.stream;
+    if (!rc) rc = cusmc_dist_create(me.ctx, kind, nullptr, V, d, df, &me.obs);
+    if (!rc) rc = me.X.reserve(slice * T * 8);
+    if (!rc) rc = me.w.reserve(rows * T * 8);
+    if (!rc) rc = me.a.reserve(rows * T * 4);
+    if (!rc) rc = me.wfull.reserve((size_t)N * 2 * 8);
+    if (!rc) rc = me.anc.reserve(slice * 8);
+    if (!rc) rc = me.ident.reserve(rows * 4);
+    double *X = (double *)me.X.p, *w = (double *)me.w.p, *wfull = (double *)me.wfull.p;
+    uint32_t *a = (uint32_t *)me.a.p;
+    if (!rc) {
+      std::vector<uint32_t> id(rows);
+      for (size_t i = 0; i < rows; ++i) id[i] = (uint32_t)i;
+      const std::vector<double> w0(N, 1.0 / (double)N);  // initialize(): w_0 = 1/N  (src/mcmc.cpp:85)
+      rc = hip(hipMemcpyAsync(me.ident.p, id.data(), rows * 4, hipMemcpyHostToDevice, me.stream), "upload");
+      if (!rc) rc = hip(hipMemcpyAsync(wfull, w0.data(), (size_t)N * 8, hipMemcpyHostToDevice, me.stream), "upload");
+      if (!rc) rc = hip(hipMemcpyAsync(w, w0.data(), rows * 8, hipMemcpyHostToDevice, me.stream), "upload");
+      if (!rc) rc = hip(hipMemsetAsync(a, 0, rows * 4, me.stream), "memset");
+      if (!rc) rc = cusmc_initialize_dev(me.ctx, kind, df, m0, Q0.data(), d, scale, seed, me.first, me.count, X);
+      if (!rc) rc = hip(hipStreamSynchronize(me.stream), "initial state");
+    }
+    guard(rc);
+    barrier.wait();  // every shard's buffers exist and hold step 0
+    // ---- MCMC(): for t = 1..T-1: resample -> (fetch ancestors) -> propagate -> reweight
+    for (uint32_t t = 1; t < T; ++t) {
+      if (!abort_run.load()) {
+        const double *w_prev = wfull + (size_t)((t - 1) & 1) * N;
+        uint32_t *a_t = a + (size_t)t * rows;
+        double *X_t = X + (size_t)t * slice, *w_t = w + (size_t)t * rows;
+        rc = cusmc_metropolis_dev(me.ctx, w_prev, N, B, seed, t, me.first, me.count, a_t);
+        if (!rc) {
+          cusmc::ShardTable tab;
+          tab.n = ndev;
+          for (int s2 = 0; s2 < ndev; ++s2) {
+            tab.base[s2] = (const double *)sh[s2].X.p + (size_t)(t - 1) * sh[s2].count * d;
+            tab.first[s2] = sh[s2].first;
+          }
+          tab.first[ndev] = N;
+          rc = hip(cusmc::launch_gather_rows_sharded(tab, a_t, me.count, d, (double *)me.anc.p, me.ctx->num_cus, me.stream),
+                   "ancestor gather");
+        }
+        if (!rc)
+          rc = draws(me.ctx, kind, df, (const double *)me.anc.p, (const uint32_t *)me.ident.p, G, Qw.data(), nullptr, d, scale,
+                     seed, t, 2u, me.first, me.count, X_t);
+        if (!rc) rc = cusmc_dist_reweight_dev(me.obs, X_t, me.count, d, Y + (size_t)t * d, F, CUSMC_OUT_DENSITY, w_t);
+        for (int s2 = 0; s2 < ndev && !rc; ++s2) {
+          double *dst = (double *)sh[s2].wfull.p + (size_t)(t & 1) * N + me.first;
+          rc = hip(sh[s2].device == me.device
+                       ? hipMemcpyAsync(dst, w_t, rows * 8, hipMemcpyDeviceToDevice, me.stream)
+                       : hipMemcpyPeerAsync(dst, sh[s2].device, w_t, me.device, rows * 8, me.stream),
+                   "weight exchange");
+        }
+        if (!rc) rc = hip(hipStreamSynchronize(me.stream), "filter step");
+        guard(rc);
+      }
+      barrier.wait();  // w_t is complete on every device, x_t on its owner
+    }
+    // ---- this shard's columns of the history, in the reference's packing (src/run.rcpp.cpp:110-125)
+    if (!abort_run.load()) {
+      rc = CUSMC_OK;
+      if (X_out)
+        rc = hip(hipMemcpy2DAsync(X_out + (size_t)me.first * d, (size_t)N * d * 8, X, slice * 8, slice * 8, T,
+                                  hipMemcpyDeviceToHost, me.stream), "history copy");
+      if (!rc && w_out)
+        rc = hip(hipMemcpy2DAsync(w_out + me.first, (size_t)N * 8, w, rows * 8, rows * 8, T, hipMemcpyDeviceToHost, me.stream),
+                 "history copy");
+      if (!rc && a_out)
+        rc = hip(hipMemcpy2DAsync(a_out + me.first, (size_t)N * 4, a, rows * 4, rows * 4, T, hipMemcpyDeviceToHost, me.stream),
+                 "history copy");
+      if (!rc) rc = hip(hipStreamSynchronize(me.stream), "history copy");
+      guard(rc);
+    }
+    barrier.wait();  // nobody frees a buffer a peer may still be reading
+    if (me.stream) (void)hipStreamSynchronize(me.stream);
+    me.X.release(); me.w.release(); me.a.release(); me.wfull.release(); me.anc.release(); me.ident.release();
+    if (me.obs) cusmc_dist_destroy(me.obs);
+    if (me.ctx) {
+      me.ctx->stream = nullptr;
+      cusmc_ctx_destroy(me.ctx);
+    }
+    if (me.stream) (void)hipStreamDestroy(me.stream);
+  };
+
+  std::vector<std::thread> threads;
+  for (int r = 1; r < ndev; ++r) threads.emplace_back(worker, r);
+  worker(0);
+  for (auto &th : threads) th.join();
+  for (int r = 0; r < ndev; ++r)
+    if (sh[r].rc) {
+      g_last_error = sh[r].error;
+      return sh[r].rc;
+    }
+  return CUSMC_OK;
 }

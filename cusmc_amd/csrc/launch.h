@@ -147,6 +147,17 @@ hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const uint32
                           uint32_t first, uint32_t count, uint32_t *a_out, double *X_out,
                           double *w_out, int num_cus, hipStream_t stream);
 
+// --- kernels/gather.hip : ancestor rows of a particle array sharded over devices -----------------------
+constexpr int kMaxShards = 16;
+struct ShardTable {
+  const double *base[kMaxShards];    // shard r's rows of x_{t-1} (a pointer valid on the launching device)
+  uint32_t first[kMaxShards + 1];    // shard r owns particles [first[r], first[r+1])
+  int n;
+};
+// out[i][:] = x[a[i]][:] for i < count, row a[i] read from the shard that owns it
+hipError_t launch_gather_rows_sharded(const ShardTable &tab, const uint32_t *a, uint32_t count, int d, double *out,
+                                      int num_cus, hipStream_t stream);
+
 // --- kernels/percov.hip : per-particle covariances, d <= 16 (lane = matrix, triangle in LDS) -------
 bool percov_supported(int d);
 hipError_t launch_cholesky_batched(const double *S, int64_t N, int d, double *L, double *logdet, int *info,

@@ -225,6 +225,19 @@ int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32
                       const char *distribution, uint32_t B, double scale, uint64_t seed,
                       double *X_out, double *w_out, uint32_t *a_out);
 
+/* The same filter with the particles sharded over `ndev` GPUs of one node (contiguous shards, one host
+ * thread + context per device, peer access over xGMI) -- the loop of src/mcmc.cpp:292-308 being sharded;
+ * the reference has no multi-device code.  Exact algorithm and bit-identical results: every draw is keyed
+ * by the global particle index.  Per step a device receives the other shards' weights (8 (N - N/R)
+ * bytes) and only the rows x_{t-1}[a_i] its own ancestors name (at most 8 d N/R bytes).  A device may be
+ * listed more than once (several shards on one GPU: how a one-GPU box rehearses this path).
+ * cusmc_pf_run_host itself takes this route when the environment holds CUSMC_DEVICES="0,1,...". */
+int cusmc_pf_run_multi_host(const int *devices, int ndev, const double *Y, uint32_t N, int d, uint32_t T,
+                            const double *m0, const double *C0, const double *F, const double *G,
+                            const double *V, const double *W, float df, const char *resampler,
+                            const char *distribution, uint32_t B, double scale, uint64_t seed,
+                            double *X_out, double *w_out, uint32_t *a_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,36 +21,28 @@ Eigen::VectorXd MVN(Eigen::VectorXd mu, Eigen::MatrixXd sigma)
   // statistically correct draw with Q = eigen square root; options(CuSMC.compat = TRUE)
   // restores the reference's distribution.
   const int d = (int)mu.size();
+  if (sigma.rows() != d || sigma.cols() != d) Rcpp::stop("sigma must be %d x %d", d, d);
   const bool compat = Rcpp::as<bool>(Rcpp::Function("getOption")("CuSMC.compat", false));
-  RowMatrix Q(d, d);
-  if (compat) {
-    Q = sigma;
-  } else {
-    const RowMatrix s = sigma;
-    check(cusmc_eigen_sqrt(s.data(), d, Q.data()));
-  }
-  const Stream st = next_stream();
+  const RowMatrix Q = compat ? RowMatrix(sigma) : session().eigen_sqrt(sigma);
   Eigen::VectorXd draws(d);
   check(cusmc_sample_host(context(), CUSMC_MVN, 0.f, mu.data(), Q.data(), d, compat ? std::sqrt(3.0) : 1.0,
-                          st.seed, st.call, 1, draws.data()));
+                          next_key(), 0, 1, draws.data()));
   return draws;
 }
 
 //' MultiVariateNormal Probability Density Function
 //'
-//' @param x      [vector | d x N matrix]: point, or particles in columns.
+//' @param x      [vector | d x N matrix]: one point (returns one number, as the reference), or particles in columns.
 //' @param mu     [vector]: Mean vector.
 //' @param sigma  [matrix]: Covariance matrix.
 //' @return       [numeric]: density (one value per column of x)
 //' @export
 // [[Rcpp::export]]
-Eigen::VectorXd MVNPDF(Eigen::MatrixXd x, Eigen::VectorXd mu, Eigen::MatrixXd sigma)
+SEXP MVNPDF(SEXP x, Eigen::VectorXd mu, Eigen::MatrixXd sigma)
 {
-  // reference: F = I; MVN(mu, sigma).pdf(x, F)  (src/mvn_dist.rcpp.cpp:52-58).  A d x N
-  // column-major matrix IS the ABI's N x d row-major batch: no repacking.
-  if (x.rows() != mu.size()) Rcpp::stop("x has %d rows, mu has %d entries", (int)x.rows(), (int)mu.size());
-  Dist dist(CUSMC_MVN, &mu, sigma, 0.f);
-  Eigen::VectorXd out(x.cols());
-  check(cusmc_dist_pdf_host(dist.h, x.data(), x.cols(), x.rows(), nullptr, CUSMC_OUT_DENSITY, out.data()));
-  return out;
+  // reference: double MVNPDF(VectorXd x, ...): F = I; MVN(mu, sigma).pdf(x, F)  (src/mvn_dist.rcpp.cpp:52-58).
+  // x stays a SEXP so that the documented call MVNPDF(c(0, 0), c(0, 0), diag(2)) -- a numeric WITHOUT a dim
+  // attribute, which RcppEigen's MatrixXd importer refuses -- returns its one number as before, and a
+  // d x N matrix returns N (glue.hpp: density()).  The distribution object comes from the session's cache.
+  return density(session().distribution(CUSMC_MVN, mu, sigma, 0.f), x, (int)mu.size());
 }

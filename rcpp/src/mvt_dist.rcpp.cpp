@@ -19,31 +19,26 @@ Eigen::VectorXd MVT(Eigen::VectorXd mu, Eigen::MatrixXd sigma, float nu)
   // reference: Q = eigenvectors * sqrt(eigenvalues), MVT.sample(draws, Q, 200), with one
   // sqrt(nu/chi2) PER COMPONENT (src/mvt_dist.rcpp.cpp:35-47, src/statistics.cc.cpp:385-386,411)
   const int d = (int)mu.size();
+  if (sigma.rows() != d || sigma.cols() != d) Rcpp::stop("sigma must be %d x %d", d, d);
   const bool compat = Rcpp::as<bool>(Rcpp::Function("getOption")("CuSMC.compat", false));
-  const RowMatrix s = sigma;
-  RowMatrix Q(d, d);
-  check(cusmc_eigen_sqrt(s.data(), d, Q.data()));
-  const Stream st = next_stream();
+  const RowMatrix &Q = session().eigen_sqrt(sigma);
   Eigen::VectorXd draws(d);
   check(cusmc_sample_host(context(), CUSMC_MVT, nu, mu.data(), Q.data(), d, compat ? std::sqrt(3.0) : 1.0,
-                          st.seed, st.call, 1, draws.data()));
+                          next_key(), 0, 1, draws.data()));
   return draws;
 }
 
 //' MultiVariate T Probability Density Function
 //'
-//' @param x      [vector | d x N matrix]: point, or particles in columns.
+//' @param x      [vector | d x N matrix]: one point (returns one number, as the reference), or particles in columns.
 //' @param mu     [vector]: Location vector.
 //' @param sigma  [matrix]: Dispersion matrix.
 //' @param nu     [float]: degrees of freedom.
 //' @return       [numeric]: density (one value per column of x)
 //' @export
 // [[Rcpp::export]]
-Eigen::VectorXd MVTPDF(Eigen::MatrixXd x, Eigen::VectorXd mu, Eigen::MatrixXd sigma, float nu)
+SEXP MVTPDF(SEXP x, Eigen::VectorXd mu, Eigen::MatrixXd sigma, float nu)
 {
-  if (x.rows() != mu.size()) Rcpp::stop("x has %d rows, mu has %d entries", (int)x.rows(), (int)mu.size());
-  Dist dist(CUSMC_MVT, &mu, sigma, nu);  // src/mvt_dist.rcpp.cpp:60-66
-  Eigen::VectorXd out(x.cols());
-  check(cusmc_dist_pdf_host(dist.h, x.data(), x.cols(), x.rows(), nullptr, CUSMC_OUT_DENSITY, out.data()));
-  return out;
+  // reference: double MVTPDF(VectorXd x, ...)  (src/mvt_dist.rcpp.cpp:60-66); x as in MVNPDF
+  return density(session().distribution(CUSMC_MVT, mu, sigma, nu), x, (int)mu.size());
 }

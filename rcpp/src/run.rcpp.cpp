@@ -58,16 +58,17 @@ List run(unsigned &N, unsigned &d, unsigned &timeSteps, Eigen::MatrixXd Y, Eigen
   if (Y.rows() != (int)d || Y.cols() != (int)timeSteps) Rcpp::stop("Y must be d x timeSteps");
   const RowMatrix Yt = Y.transpose();  // row t = y_t (the reference stores Y.col(t): :91)
   const RowMatrix C0r = C0, Fr = F, Gr = G, Vr = V, Wr = W;
-  const Stream st = next_stream();
+  const uint64_t key = next_key();  // a fresh Philox key per call: repeated run()s are independent replications
   std::vector<double> X((size_t)timeSteps * N * d), w((size_t)timeSteps * N);
 
   Rcpp::Rcout << "Simulating... " << std::flush;  // src/particle_filter.cpp:30
   // df goes to the filter AS df: the reference passes runtime/resampler/distribution/df in the
   // wrong slots (src/run.rcpp.cpp:100-106 vs inst/include/particle_filter.hpp:12-19).
-  // B = 10 is mcmc.cpp:291.
+  // B = 10 is mcmc.cpp:291.  With CUSMC_DEVICES="0,1,..." in the environment the same call shards the
+  // particles over those GPUs below the C ABI (include/cusmc_hip.h: cusmc_pf_run_multi_host).
   check(cusmc_pf_run_host(context(), Yt.data(), N, (int)d, timeSteps, m0.data(), C0r.data(), Fr.data(),
                           Gr.data(), Vr.data(), Wr.data(), df, resampler.c_str(), distribution.c_str(), 10,
-                          1.0, st.seed, X.data(), w.data(), nullptr));
+                          1.0, key, X.data(), w.data(), nullptr));
   Rcpp::Rcout << "Done." << std::endl;
   writeOutput(Yt, w, X, N, d, timeSteps, p);
 

@@ -1,7 +1,5 @@
 // R export metropolis_hastings() over libcusmc_hip -- replaces src/samplers.rcpp.cpp and the
 // inner loop of src/samplers.cpp (registered symbol _CuSMC_metropolis_hastings (3)).
-#include <cstdlib>
-#include <random>
 #include <vector>
 
 #include "glue.hpp"
@@ -9,26 +7,6 @@
 using namespace cusmc_glue;
 
 // [[Rcpp::depends(RcppEigen)]]
-
-namespace cusmc_glue {
-Stream next_stream()
-{
-  static bool init = false;
-  static uint64_t seed = 0;
-  static uint32_t calls = 0;
-  if (!init) {
-    const char *env = std::getenv("CUSMC_SEED");
-    if (env) {
-      seed = std::strtoull(env, nullptr, 10);
-    } else {
-      std::random_device rd;
-      seed = ((uint64_t)rd() << 32) | rd();
-    }
-    init = true;
-  }
-  return Stream{seed, ++calls};
-}
-}  // namespace cusmc_glue
 
 //' Metropolis Hastings Sampler
 //'
@@ -46,9 +24,8 @@ Eigen::VectorXd metropolis_hastings(Eigen::VectorXd w, int N, int B)
   // (src/samplers.rcpp.cpp:38-49)
   if (N < 0 || N > w.size()) Rcpp::stop("N = %d exceeds the %d weights given", N, (int)w.size());
   if (B < 0) Rcpp::stop("B must be non-negative");
-  const Stream st = next_stream();
   std::vector<uint32_t> a((size_t)N);
-  check(cusmc_metropolis_host(context(), w.data(), (uint32_t)N, (uint32_t)B, st.seed, st.call, a.data()));
+  check(cusmc_metropolis_host(context(), w.data(), (uint32_t)N, (uint32_t)B, next_key(), 1, a.data()));
   Eigen::VectorXd out(N);
   for (int i = 0; i < N; ++i) out[i] = (double)a[i];
   return out;

@@ -69,6 +69,13 @@ def test_no_device_fails_loudly_not_silently():
         cusmc_amd.MVNPDF([0.0, 0.0], [0.0, 0.0], np.eye(2))
     with pytest.raises(cusmc_amd.CusmcError):
         cusmc_amd.metropolis_hastings([0.0, 0.0], 2, 10)
+    I = np.eye(2)
+    with pytest.raises(cusmc_amd.CusmcError) as e:  # the multi-device entry validates, then refuses too
+        cusmc_amd.run(8, 2, 3, np.zeros((2, 3)), np.zeros(2), I, I, I, I, I, 0.0, "metropolis", "mvn", seed=1, devices=[0, 0])
+    assert e.value.code == _lib.ENODEVICE
+    with pytest.raises(cusmc_amd.CusmcError) as e:
+        cusmc_amd.run(8, 2, 3, np.zeros((2, 3)), np.zeros(2), I, I, I, I, I, 0.0, "bootstrap", "mvn", seed=1, devices=[0, 0])
+    assert e.value.code == _lib.EINVAL and "resampler" in str(e.value)
 
 
 def test_null_arguments_are_rejected_without_a_device():

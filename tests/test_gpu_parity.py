@@ -957,6 +957,48 @@ def test_sharded_filter_on_gpu_equals_run(cs, tmp_path, N, d, exchange):
     assert np.array_equal(got["w"], res["weights"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d,T,dist,nu,ndev", [(5003, 2, 6, "mvn", 0.0, 2), (3001, 16, 5, "mvn", 0.0, 2),
+                                                (2003, 64, 4, "mvt", 4.0, 3), (40000, 8, 4, "mvn", 0.0, 2),
+                                                (1201, 130, 3, "mvn", 0.0, 2)])
+def test_multi_device_run_below_the_abi_equals_one_device(cs, N, d, T, dist, nu, ndev):
+    """cusmc_pf_run_multi_host: the filter's time loop sharded over a device list BELOW the C ABI (one host
+    thread + context per shard, weights exchanged by peer copies, only the ancestor rows fetched from their
+    owners).  Rehearsed here with every shard on device 0; the history is bitwise the one-device
+    cusmc_pf_run_host result (ragged shards, fused and unfused single-device paths, dense F and G)."""
+    rng = np.random.default_rng(N + d)
+    Y = np.cumsum(0.1 * rng.standard_normal((d, T)), axis=1)
+    G = 0.9 * np.eye(d) + 0.05 * rng.standard_normal((d, d)) / np.sqrt(d)
+    F = np.eye(d) + 0.05 * rng.standard_normal((d, d)) / np.sqrt(d)
+    V, W, C0 = spd(rng, d), 0.3 * spd(rng, d), spd(rng, d)
+    m0 = rng.standard_normal(d)
+    args = (N, d, T, Y, m0, C0, F, G, V, W, nu, "metropolis", dist)
+    one = cs.run(*args, seed=31, return_ancestors=True)
+    many = cs.run(*args, seed=31, return_ancestors=True, devices=[0] * ndev)
+    for k in ("ancestors", "posterior_x", "weights"):
+        assert np.array_equal(one[k], many[k]), k
+
+
+@pytest.mark.gpu
+def test_cusmc_devices_environment_shards_run(cs, monkeypatch):
+    """CUSMC_DEVICES in the environment routes the plain entry point (what rcpp/src/run.rcpp.cpp calls)
+    through the multi-device loop; malformed lists are refused."""
+    I = np.eye(2)
+    Y = np.cumsum(0.1 * np.random.default_rng(2).standard_normal((2, 5)), axis=1)
+    args = (4001, 2, 5, Y, np.zeros(2), I, I, 0.9 * I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn")
+    one = cs.run(*args, seed=8, return_ancestors=True)
+    monkeypatch.setenv("CUSMC_DEVICES", "0,0,0")
+    env = cs.run(*args, seed=8, return_ancestors=True)
+    for k in ("ancestors", "posterior_x", "weights"):
+        assert np.array_equal(one[k], env[k]), k
+    monkeypatch.setenv("CUSMC_DEVICES", "0;1")
+    with pytest.raises(cs.CusmcError):
+        cs.run(*args, seed=8)
+    monkeypatch.setenv("CUSMC_DEVICES", "0,99")
+    with pytest.raises(cs.CusmcError):
+        cs.run(*args, seed=8)
+
+
 # --- per-particle covariances (SURVEY.md 8(f) row 4) ---------------------------------------------
 
 def _random_covariances(rng, N, d):
