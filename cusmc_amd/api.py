@@ -593,7 +593,6 @@ def run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p=0
             raise ValueError("%s must be %d x %d, got %s" % (name, d, d, m.shape))
     if m0.reshape(-1).shape[0] != d:
         raise ValueError("m0 must have %d entries" % d)
-    ctx = default_context()
     X = np.empty((T, N, d))
     w = np.empty((T, N))
     a = np.empty((T, N), dtype=np.uint32) if return_ancestors else None  # (not copied back unless asked for)
@@ -604,7 +603,7 @@ def run(N, d, timeSteps, Y, m0, C0, F, G, V, W, df, resampler, distribution, p=0
         devs = (C.c_int * len(devices))(*[int(v) for v in devices])
         check(_lib.lib().cusmc_pf_run_multi_host(devs, len(devices), *tail))
     else:
-        check(_lib.lib().cusmc_pf_run_host(ctx._h, *tail))
+        check(_lib.lib().cusmc_pf_run_host(default_context()._h, *tail))
     if write_csv:
         from .io import writeOutput
         writeOutput(Yt, w, X, N, d, T, int(p))
