@@ -385,12 +385,14 @@ static inline uint32_t uint_below(uint32_t hi, uint32_t lo, uint32_t N)
  * reference's shared declarations are a data race).
  * One Philox block per (i, n): words 0,1 -> u; words 2,3 -> j.
  * `step` plays the role of the reference's t (a_t[t*N+i] = k); the caller owns the offset. */
-ORACLE_API void oracle_metropolis(uint32_t *a, const double *w, uint32_t N, uint32_t B,
-                                  uint64_t seed, uint32_t step)
+/* chains [first, first + count) of the N: a[i - first] (what one rank of a sharded resample computes) */
+ORACLE_API void oracle_metropolis_range(uint32_t *a, const double *w, uint32_t N, uint32_t B,
+                                        uint64_t seed, uint32_t step, uint32_t first, uint32_t count)
 {
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
 #pragma omp parallel for schedule(static)
-  for (uint32_t i = 0; i < N; ++i) {
+  for (uint32_t c = 0; c < count; ++c) {
+    const uint32_t i = first + c;
     uint32_t k = i;
     double wk = w[k];
     for (uint32_t n = 0; n < B; ++n) {
@@ -401,8 +403,14 @@ ORACLE_API void oracle_metropolis(uint32_t *a, const double *w, uint32_t N, uint
       double wj = w[j];
       if (u <= wj / wk) { k = j; wk = wj; }
     }
-    a[i] = k;
+    a[c] = k;
   }
+}
+
+ORACLE_API void oracle_metropolis(uint32_t *a, const double *w, uint32_t N, uint32_t B,
+                                  uint64_t seed, uint32_t step)
+{
+  oracle_metropolis_range(a, w, N, B, seed, step, 0u, N);
 }
 
 /* exp(t) for t <= 0 as ONE fixed sequence of correctly rounded operations (reduction t = k ln2 + r,

@@ -137,14 +137,16 @@ def philox4x32_10(ctr, key):
     return out
 
 
-def metropolis(w, B, seed, step=1, N=None):
+def metropolis(w, B, seed, step=1, N=None, first=0, count=None):
     """Sampler::metropolis_hastings inner loop (src/samplers.cpp:21-35) under the build's
-    Philox contract.  Returns 0-based ancestors (uint32)."""
+    Philox contract.  Returns 0-based ancestors (uint32) of chains [first, first + count)
+    (default: all N)."""
     w = _d(w)
     N = w.shape[0] if N is None else N
-    a = np.empty(N, dtype=np.uint32)
-    lib().oracle_metropolis(_p(a), _p(w), C.c_uint32(N), C.c_uint32(B), C.c_uint64(seed),
-                            C.c_uint32(step))
+    count = N - first if count is None else count
+    a = np.empty(count, dtype=np.uint32)
+    lib().oracle_metropolis_range(_p(a), _p(w), C.c_uint32(N), C.c_uint32(B), C.c_uint64(seed),
+                                  C.c_uint32(step), C.c_uint32(first), C.c_uint32(count))
     return a
 
 

@@ -747,12 +747,11 @@ def test_filter_against_oracle_larger(cs, oracle, d, dist, nu):
     # eigen square roots are unique only up to column order/sign; both sides run the same
     # Householder tridiagonalisation + implicit QL with the same ordering and sign convention, so
     # the factors coincide and trajectories can be compared directly
-    same = np.mean(out["ancestors"] == a)
-    assert same > 0.995
-    ok = (out["ancestors"] == a).all(axis=0)  # chains whose whole ancestry agrees
-    assert ok.mean() > 0.9
-    assert np.allclose(out["posterior_x"][:, ok], X[:, ok], rtol=1e-8, atol=1e-8)
-    assert np.allclose(out["weights"][:, ok], w[:, ok], rtol=1e-6, atol=1e-300)
+    # accept/reject sequences bit-exact (north_star): the weights agree to ~1e-13, so a flipped test
+    # would need u within 1e-13 of a ratio -- any mismatch at all means something larger differs
+    assert np.array_equal(out["ancestors"], a), "%d of %d ancestors differ" % (int(np.sum(out["ancestors"] != a)), a.size)
+    assert np.allclose(out["posterior_x"], X, rtol=1e-8, atol=1e-8)
+    assert np.allclose(out["weights"], w, rtol=1e-6, atol=1e-300)
 
 
 @pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 4))
@@ -778,10 +777,9 @@ def test_filter_random_models(cs, oracle, seed):
         tag = (seed, case, d, dist, nu, T, N, general_F, dense_G, dense_W)
         out = cs.run(N, d, T, Y.T, m0, C0, F, G, V, W, nu, "metropolis", dist, seed=11 + case, return_ancestors=True)
         X, w, a = oracle.pf_run(Y, N, m0, C0, F, G, V, W, dist, nu, B=10, seed=11 + case, hoisted=True)
-        ok = (out["ancestors"] == a).all(axis=0)  # chains whose whole ancestry agrees
-        assert ok.mean() > 0.9, tag
-        assert np.allclose(out["posterior_x"][:, ok], X[:, ok], rtol=1e-8, atol=1e-8), tag
-        assert np.allclose(out["weights"][:, ok], w[:, ok], rtol=1e-6, atol=1e-300), tag
+        assert np.array_equal(out["ancestors"], a), (tag, int(np.sum(out["ancestors"] != a)))
+        assert np.allclose(out["posterior_x"], X, rtol=1e-8, atol=1e-8), tag
+        assert np.allclose(out["weights"], w, rtol=1e-6, atol=1e-300), tag
 
 
 @pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16])
