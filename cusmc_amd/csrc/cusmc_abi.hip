@@ -425,24 +425,39 @@ CUSMC_EXPORT int cusmc_ctx_create(int device, cusmc_ctx **out)
   return CUSMC_OK;
 }
 
+// Destroy functions run from finalizers -- R's at session end, Python's at interpreter exit, in any order
+// and possibly while the HIP runtime is itself shutting down.  Two rules keep that safe:
+//   (1) a distribution never dereferences a dead context: destroying the context orphans its
+//       distributions (dist->ctx = nullptr) and releases their device buffers itself.  Round 1's abort at
+//       pytest exit (`std::bad_variant_access`, thrown inside libamdhip64 -- the only library in the
+//       process besides torch that carries that type) was this: a distribution finalized AFTER its context
+//       read ctx->device / ctx->stream out of freed memory and handed the garbage to hipSetDevice /
+//       hipStreamSynchronize / hipFree, whose handle lookup threw.  DESIGN.md section 9.
+//   (2) nothing the runtime throws or returns during teardown leaves these functions: HIP status codes
+//       (hipErrorDeinitialized included) are ignored here, and a C++ exception from inside the runtime is
+//       swallowed -- the ABI promises that no exception crosses it.
 CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
 {
   if (!ctx) return CUSMC_OK;
-  (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  for (cusmc_dist *dist : ctx->dists) {
-    dist->frags.release();
-    dist->Mdev.release();
-    dist->shift.release();
-    dist->bias.release();
-    dist->ctx = nullptr;
+  try {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (cusmc_dist *dist : ctx->dists) {
+      dist->frags.release();
+      dist->Mdev.release();
+      dist->shift.release();
+      dist->bias.release();
+      dist->ctx = nullptr;
+    }
+    ctx->dists.clear();
+    for (auto &b : ctx->scratch) b.release();
+    ctx->draw_img.release();
+    ctx->whi.release();
+    ctx->step_mats.release();
+    ctx->ring.release();
+  } catch (...) {
+    for (cusmc_dist *dist : ctx->dists) dist->ctx = nullptr;  // (still orphan them: rule 1)
   }
-  ctx->dists.clear();
-  for (auto &b : ctx->scratch) b.release();
-  ctx->draw_img.release();
-  ctx->whi.release();
-  ctx->step_mats.release();
-  ctx->ring.release();
   delete ctx;
   return CUSMC_OK;
 }
@@ -518,12 +533,15 @@ CUSMC_EXPORT int cusmc_dist_destroy(cusmc_dist *dist)
 {
   if (!dist) return CUSMC_OK;
   if (cusmc_ctx *ctx = dist->ctx) {  // (null: the context went first and took the device buffers with it)
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    dist->frags.release();
-    dist->Mdev.release();
-    dist->shift.release();
-    dist->bias.release();
+    try {
+      (void)hipSetDevice(ctx->device);
+      (void)hipStreamSynchronize(ctx->stream);
+      dist->frags.release();
+      dist->Mdev.release();
+      dist->shift.release();
+      dist->bias.release();
+    } catch (...) {  // (rule 2 above)
+    }
     ctx->dists.erase(std::remove(ctx->dists.begin(), ctx->dists.end(), dist), ctx->dists.end());
   }
   delete dist;

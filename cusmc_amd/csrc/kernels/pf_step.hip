@@ -53,12 +53,15 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
       xi[j] = scale * z0;
       if (j + 1 < D) xi[j + 1] = scale * z1;
     }
+    double chi[D];
+    if (MVT)  // the particle's D chi^2 draws together (smallops.h: chi_square_batch)
+      chi_square_batch<D>(chi_setup(nu), i, step, k0, k1, [](int c) { return c; }, [](int) { return true; }, chi);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < D; ++k) s = fma(Q[j * D + k], xi[k], s);
-      if (MVT) s = fma(s, sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu)), 0.0);  // (an fma, so that no kernel contracts it with the add below)
+      if (MVT) s = fma(s, sqrt((double)nu / chi[j]), 0.0);  // (an fma, so that no kernel contracts it with the add below)
       double m = 0.0;
 #pragma unroll
       for (int k = 0; k < D; ++k) m = fma(G[j * D + k], xp[k], m);

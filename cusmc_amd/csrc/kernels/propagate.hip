@@ -106,19 +106,23 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
   const int rows_per_block = 256 >> pw_log2;
   const int lane_pr = (int)threadIdx.x & (pw - 1);
   const uint32_t lane_row = threadIdx.x >> pw_log2;
+  const ChiSquare cs = chi_setup(MVT ? nu : 2.0f);
   for (uint32_t il = blockIdx.x * rows_per_block + lane_row; il < count; il += gridDim.x * rows_per_block) {
     const uint32_t i = first + il;
     const long anc = gdiag ? (a ? (long)a[il] : (long)i) : 0;
     for (int pr = lane_pr; pr < pairs; pr += pw) {
       double z[2];
       normal_pair(philox4x32_10(i, (uint32_t)pr, step, domain, k0, k1), z[0], z[1]);
+      double chi[2] = {1.0, 1.0};
+      if (MVT)  // the pair's two chi^2 draws together (smallops.h: chi_square_batch)
+        chi_square_batch<2>(cs, i, step, k0, k1, [&](int c) { return 2 * pr + c; }, [&](int c) { return 2 * pr + c < d; }, chi);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int j = 2 * pr + c;
         if (j < d) {
           const double xi = scale * z[c];
           double s = fma(qdiag[j], xi, 0.0);
-          if (MVT) s = fma(s, sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu)), 0.0);  // (an fma, so that no kernel contracts it with the add below)
+          if (MVT) s = fma(s, sqrt((double)nu / chi[c]), 0.0);  // (an fma, so that no kernel contracts it with the add below)
           const double m = gdiag ? fma(gdiag[j], X_prev[anc * d + j], 0.0) : m0[j];
           X_out[(long)il * d + j] = s + m;
         }
@@ -234,12 +238,15 @@ __global__ __launch_bounds__(256) void propagate_small_kernel(
       xi[j] = scale * z0;
       if (j + 1 < D) xi[j + 1] = scale * z1;
     }
+    double chi[D];
+    if (MVT)  // the particle's D chi^2 draws together (smallops.h: chi_square_batch)
+      chi_square_batch<D>(chi_setup(nu), i, step, k0, k1, [](int c) { return c; }, [](int) { return true; }, chi);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < D; ++k) s = fma(Q[j * D + k], xi[k], s);
-      if (MVT) s = fma(s, sqrt((double)nu / chi_square_for(i, (uint32_t)j, step, k0, k1, nu)), 0.0);
+      if (MVT) s = fma(s, sqrt((double)nu / chi[j]), 0.0);
       double m;
       if (G) {
         m = 0.0;

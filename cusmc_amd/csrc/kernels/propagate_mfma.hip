@@ -35,35 +35,6 @@ static __device__ __forceinline__ void pm_normal_pair(const u32x4 r, double &z0,
   normal_pair(r, z0, z1);  // smallops.h: the same Box-Muller as every other draw path
 }
 
-// chi^2_nu = 2 Gamma(nu/2, 1); counter layout as oracle/cusmc_oracle.c:chi_square_for.
-static __device__ __attribute__((noinline)) double pm_chi_square(uint32_t particle, uint32_t j, uint32_t step, uint32_t k0, uint32_t k1,
-                                       float nu)
-{
-  double a = 0.5 * (double)nu;
-  double boost = 1.0;
-  if (a < 1.0) {
-    const u32x4 r = philox4x32_10(particle, j * 64u + 63u, step, 5u, k0, k1);
-    boost = pow(1.0 - u01_53(r.x, r.y), 1.0 / a);
-    a += 1.0;
-  }
-  const double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
-  double g = dd;
-  for (uint32_t m = 0; m < 63u; ++m) {
-    double z0, z1;
-    pm_normal_pair(philox4x32_10(particle, j * 64u + m, step, 3u, k0, k1), z0, z1);
-    double v = 1.0 + c * z0;
-    if (v <= 0.0) continue;
-    v = v * v * v;
-    const u32x4 r = philox4x32_10(particle, j * 64u + m, step, 5u, k0, k1);
-    const double u = 1.0 - u01_53(r.x, r.y);
-    if (ln_pos(u) < 0.5 * z0 * z0 + dd - dd * v + dd * ln_pos(v)) {
-      g = dd * v;
-      break;
-    }
-  }
-  return 2.0 * g * boost;
-}
-
 // Every 16 <= d <= 128 and any 8-byte aligned batch.  d <= 96 keeps both factors in LDS (one
 // launch); 96 < d <= 128 runs two launches, one factor each (131 KB at d = 128): first
 // x = [diag(c)] Q xi, then x += G x_prev[a].
@@ -107,6 +78,7 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
   if (threadIdx.x == 0) *sNext = 0;
   __syncthreads();
 
+  const ChiSquare cs = chi_setup(MVT ? nu : 2.0f);
   const int lane = threadIdx.x & 63;
   const int p = lane & 15, h = lane >> 4;
   const long G_ = gridDim.x;
@@ -201,14 +173,28 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
     // x_out[p][16 cb + h + 4 r]
     if (live) {
       double *dst = X_out + local * d + h;
+      // the lane's chi^2 draws, four output blocks (16 components: 16 cb + h + 4 r at c = 4 (cb - cb0) + r) at a
+      // time: first attempt and squeeze for all of them, then the few still open one per trip
+      // (smallops.h: chi_square_batch); groups of four blocks bound the registers the draws hold
+      // (fewer draws per batch where registers are short: 4 NB results would spill from d = 64 up)
+      constexpr int GB = NB < 4 ? NB : 2;
+      double chi[(MVT && HAS_Q) ? 4 * GB : 1];
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
+        if constexpr (MVT && HAS_Q) {
+          if (cb % GB == 0) {
+            const int cb0 = cb;
+            chi_square_batch<4 * GB>(cs, gi, step, k0, k1, [&](int c) { return 16 * (cb0 + (c >> 2)) + h + 4 * (c & 3); },
+                                     [&](int c) { return cb0 + (c >> 2) < NB && (!PAD || 16 * (cb0 + (c >> 2)) + h + 4 * (c & 3) < d); },
+                                     chi);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * cb + h + 4 * r;
           if (PAD && j >= d) continue;
           double v = HAS_Q ? accQ[cb][r] : dst[16 * cb + 4 * r];
-          if (MVT && HAS_Q) v *= sqrt((double)nu / pm_chi_square(gi, (uint32_t)j, step, k0, k1, nu));
+          if constexpr (MVT && HAS_Q) v *= sqrt((double)nu / chi[4 * (cb % GB) + r]);
           if (SPLIT_ACC) v += accG[cb][r];
           if (DIAG_G) v += fma(sG[j], xc[cb][r], 0.0);  // (the one non-zero term of the dense kernels' sum)
           dst[16 * cb + 4 * r] = v;

@@ -101,34 +101,123 @@ static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, do
   z1 = rad * s;
 }
 
-// chi^2_nu = 2 Gamma(nu/2, 1) by Marsaglia-Tsang (the reference's device sampler,
-// src/mvt_dist.cu.cpp:20-61); counter layout as oracle/cusmc_oracle.c:chi_square_for.
-static __device__ __attribute__((noinline)) double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, uint32_t k0,
-                                        uint32_t k1, float nu)
+// chi^2_nu = 2 Gamma(nu/2, 1) by Marsaglia-Tsang, the reference's device sampler (curand_gamma,
+// src/mvt_dist.cu.cpp:20-61) including its squeeze test (:45); counter layout as
+// oracle/cusmc_oracle.c:chi_square_for -- attempt m < 63 of (particle, component j) takes its normal from
+// Philox block (particle, 64 j + m, step, 3) and its uniform from block (particle, 64 j + m, step, 5); the
+// a < 1 boost uniform is block (particle, 64 j + 63, step, 5).  Accept attempt m iff
+//     v = 1 + c z0 > 0   and   ( u < 1 - 0.0331 z0^4   or   ln u < z0^2/2 + dd - dd v^3 + dd ln v^3 ).
+//
+// Cost model (f64 MFMA kernels: every VALU instruction is on the critical path; elsewhere: the proposal
+// kernels are RNG-bound).  One attempt is two Philox blocks and a Box-Muller pair; the log test adds two
+// ln.  The squeeze settles ~92 % of the attempts without a logarithm, ~96 % of the attempts accept -- but a
+// wave runs a branch as long as ONE of its 64 lanes needs it, so a per-draw loop executes its slow path on
+// nearly every draw (1 - 0.92^64) and its second attempt on most (1 - 0.96^64): ~2 x (attempt + 2 ln) per
+// draw, which is what round 1's version cost (29 x the Normal draw in the d = 2 filter).  chi_square_batch
+// therefore takes the K draws of a lane TOGETHER: first attempt and squeeze for all K with no branch, then
+// the few draws still open (8 % per lane: the wave makes max-over-lanes trips, ~4 of 16) go through the full
+// loop one per trip.  Same counters, same accept rule, same results as the draw-by-draw loop.
+struct ChiSquare {
+  double dd, c, inv_a;
+  bool boost;
+};
+static __device__ __forceinline__ ChiSquare chi_setup(float nu)
 {
+  ChiSquare cs;
   double a = 0.5 * (double)nu;
-  double boost = 1.0;
-  if (a < 1.0) {
-    const u32x4 r = philox4x32_10(particle, j * 64u + 63u, step, 5u, k0, k1);
-    boost = pow(1.0 - u01_53(r.x, r.y), 1.0 / a);
-    a += 1.0;
-  }
-  const double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
-  double g = dd;
+  cs.boost = a < 1.0;
+  cs.inv_a = 1.0 / a;
+  if (cs.boost) a += 1.0;
+  cs.dd = a - 1.0 / 3.0;
+  cs.c = 1.0 / sqrt(9.0 * cs.dd);
+  return cs;
+}
+// attempt (particle, jm = 64 j + m): its normal, v = 1 + c z0, and its uniform in (0, 1]
+static __device__ __forceinline__ void chi_attempt(const ChiSquare &cs, uint32_t particle, uint32_t jm, uint32_t step,
+                                                   uint32_t k0, uint32_t k1, double &z0, double &v, double &u)
+{
+  double z1;
+  normal_pair(philox4x32_10(particle, jm, step, 3u, k0, k1), z0, z1);
+  v = 1.0 + cs.c * z0;
+  const u32x4 r = philox4x32_10(particle, jm, step, 5u, k0, k1);
+  u = 1.0 - u01_53(r.x, r.y);
+}
+// u < 1 - 0.0331 z0^4, as ONE fixed sequence of roundings (the oracle evaluates the same fma)
+static __device__ __forceinline__ bool chi_squeeze(double z0, double u)
+{
+  const double z2 = z0 * z0;
+  return u < fma(-(0.0331 * z2), z2, 1.0);
+}
+// the draw-by-draw loop: every attempt from m = 0 with the full rule; returns Gamma(a, 1) / boost
+static __device__ __forceinline__ double chi_loop(const ChiSquare &cs, uint32_t particle, uint32_t j, uint32_t step,
+                                                  uint32_t k0, uint32_t k1)
+{
+  double g = cs.dd;  // value if all 63 attempts reject (probability < 1e-60)
   for (uint32_t m = 0; m < 63u; ++m) {
-    double z0, z1;
-    normal_pair(philox4x32_10(particle, j * 64u + m, step, 3u, k0, k1), z0, z1);
-    double v = 1.0 + c * z0;
+    double z0, v, u;
+    chi_attempt(cs, particle, j * 64u + m, step, k0, k1, z0, v, u);
     if (v <= 0.0) continue;
     v = v * v * v;
-    const u32x4 r = philox4x32_10(particle, j * 64u + m, step, 5u, k0, k1);
-    const double u = 1.0 - u01_53(r.x, r.y);
-    if (ln_pos(u) < 0.5 * z0 * z0 + dd - dd * v + dd * ln_pos(v)) {
-      g = dd * v;
+    if (chi_squeeze(z0, u) || ln_pos(u) < 0.5 * z0 * z0 + cs.dd - cs.dd * v + cs.dd * ln_pos(v)) {
+      g = cs.dd * v;
       break;
     }
   }
-  return 2.0 * g * boost;
+  return g;
+}
+static __device__ __forceinline__ double chi_boost(const ChiSquare &cs, uint32_t particle, uint32_t j, uint32_t step,
+                                                   uint32_t k0, uint32_t k1)
+{
+  const u32x4 r = philox4x32_10(particle, j * 64u + 63u, step, 5u, k0, k1);
+  return pow(1.0 - u01_53(r.x, r.y), cs.inv_a);
+}
+// chi[c] = chi^2_nu draw of component jof(c) for the c < K with live(c); jof / live are evaluated for
+// run-time c as well (closed forms, not tables: no dynamically indexed registers).
+template <int K, typename JOf, typename Live>
+static __device__ __forceinline__ void chi_square_batch(const ChiSquare &cs, uint32_t particle, uint32_t step, uint32_t k0,
+                                                        uint32_t k1, JOf jof, Live live, double (&chi)[K])
+{
+  static_assert(K <= 32, "one pending bit per draw");
+  uint32_t pend = 0;
+#pragma unroll
+  for (int c = 0; c < K; ++c) chi[c] = 1.0;
+  // A real loop, not K unrolled copies: unrolled, the K independent attempts are interleaved by the
+  // scheduler and their ~50 live registers each add up (100-200 VGPRs spilled in the matrix-core proposal);
+  // the price is the select chain that files the result under a run-time c.
+#pragma unroll 1
+  for (int c = 0; c < K; ++c) {
+    if (!live(c)) continue;
+    double z0, v, u;
+    chi_attempt(cs, particle, (uint32_t)jof(c) * 64u, step, k0, k1, z0, v, u);
+    const bool ok = (v > 0.0) & chi_squeeze(z0, u);
+    const double g = cs.dd * (v * v * v);
+    pend |= ok ? 0u : 1u << c;
+#pragma unroll
+    for (int cc = 0; cc < K; ++cc) chi[cc] = cc == c ? g : chi[cc];
+  }
+  while (pend) {  // one open draw per lane per trip
+    const int c = __builtin_ctz(pend);
+    pend &= pend - 1u;
+    const double g = chi_loop(cs, particle, (uint32_t)jof(c), step, k0, k1);
+#pragma unroll
+    for (int cc = 0; cc < K; ++cc) chi[cc] = cc == c ? g : chi[cc];
+  }
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    chi[c] *= 2.0;
+    if (cs.boost) {  // (wave-uniform: nu is a launch parameter)
+      if (live(c)) chi[c] *= chi_boost(cs, particle, (uint32_t)jof(c), step, k0, k1);
+    }
+  }
+}
+// a single draw (callers that own one component per lane)
+static __device__ __forceinline__ double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, uint32_t k0,
+                                                        uint32_t k1, float nu)
+{
+  const ChiSquare cs = chi_setup(nu);
+  double chi[1];
+  chi_square_batch<1>(cs, particle, step, k0, k1, [&](int) { return j; }, [](int) { return true; }, chi);
+  return chi[0];
 }
 
 // One Metropolis chain (Sampler::metropolis_hastings, src/samplers.cpp:21-35):

@@ -485,7 +485,7 @@ static void normals_for(uint32_t particle, uint32_t step, uint32_t domain, const
 }
 
 /* chi^2_nu = 2 * Gamma(nu/2, 1), Marsaglia-Tsang squeeze with the a<1 boost, the sampler the
- * reference's device helper uses (src/mvt_dist.cu.cpp:20-61; the CPU path uses libstdc++'s
+ * reference's device helper uses, squeeze included (src/mvt_dist.cu.cpp:20-61; the CPU path uses libstdc++'s
  * chi_squared_distribution, src/statistics.cc.cpp:366,385).  The counter advance is
  * deterministic: attempt m < 63 of (particle, component j) takes its normal from block
  * (particle, j*64+m, step, 3) and its accept-uniform from block (particle, j*64+m, step, 5);
@@ -514,7 +514,11 @@ static double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, const
     ctr[3] = 5u;
     oracle_philox4x32_10(ctr, key, r);
     double u = 1.0 - u01_53(r[0], r[1]);
-    if (log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) { g = dd * v; break; }
+    /* the reference's squeeze (src/mvt_dist.cu.cpp:45), u < 1 - 0.0331 z0^4 as one fixed sequence of roundings
+     * (the kernels evaluate the same fma: smallops.h chi_squeeze), then its log test (:48) */
+    const double z2 = z0 * z0;
+    if (u < fma(-(0.0331 * z2), z2, 1.0) ||
+        log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) { g = dd * v; break; }
   }
   return 2.0 * g * boost;
 }

@@ -1,5 +1,8 @@
+import importlib.util
 import os
-import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
-from conftest import *  # noqa: F401,F403  (the suite's own fixtures: oracle, golden, spd ...)
+_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_spec = importlib.util.spec_from_file_location("suite_conftest", os.path.join(_root, "tests", "conftest.py"))
+_suite = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_suite)
+oracle, golden, spd = _suite.oracle, _suite.golden, _suite.spd  # the suite's own fixtures / helpers

@@ -25,7 +25,7 @@ def test_passes_first_with_the_oracle_loaded(cs, oracle):
 def test_fails_with_live_handles(cs, dist, nu):
     import torch
     from cusmc_amd import api
-    from conftest import spd
+    from conftest import spd  # (this directory's conftest re-exports the suite's)
     rng = np.random.default_rng(3)
     d, N, B, seed, step = 2, 20000, 10, 5, 3
     G, Q = 0.9 * np.eye(d), 0.3 * np.eye(d)
