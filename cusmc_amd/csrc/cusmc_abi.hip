@@ -771,6 +771,32 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
                                          count, X_out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
+  if (cusmc::propagate_mfma_wide_supported(d, X_prev_dev, X_out_dev)) {
+    // 128 < d <= 256: matrix cores with the output blocks split over the waves (kernels/propagate_mfma_wide.hip).
+    // device image: [frags(Q) | frags(G) or diag(G) or m0], factors zero-padded to 16*ceil(d/16)
+    const int nb = (d + 15) / 16, dp = 16 * nb;
+    const size_t nf = (size_t)cusmc::mfma_num_frags(nb, false) * 64;
+    const bool g_diag = G && cusmc::la::is_diagonal(G, d);
+    const int mode = !G ? 0 : g_diag ? 4 : 1;
+    if (int rc = image(mode == 1 ? 6 : mode == 4 ? 7 : 8, nf + (mode == 1 ? nf : (size_t)dp), [&](std::vector<double> &img) {
+          std::vector<double> Mp;
+          auto pack = [&](const double *M, double *dst) {
+            if (dp == d) { cusmc::mfma_pack_frags(M, d, false, dst); return; }
+            Mp.assign((size_t)dp * dp, 0.0);
+            for (int i = 0; i < d; ++i) std::copy(M + (size_t)i * d, M + (size_t)(i + 1) * d, Mp.begin() + (size_t)i * dp);
+            cusmc::mfma_pack_frags(Mp.data(), dp, false, dst);
+          };
+          pack(Q, img.data());
+          if (mode == 1) pack(G, img.data() + nf);
+          else if (mode == 4) for (int j = 0; j < d; ++j) img[nf + j] = G[(size_t)j * d + j];
+          else if (m0) std::copy(m0, m0 + d, img.begin() + nf);
+        }))
+      return rc;
+    const double *base = (const double *)ctx->draw_img.p;
+    HIP_TRY(cusmc::launch_propagate_mfma_wide(kind, nu, X_prev_dev, a_dev, base, base + nf, mode, d, scale, seed, step, domain,
+                                              first, count, X_out_dev, ctx->num_cus, ctx->stream));
+    return CUSMC_OK;
+  }
   if (d > 128) {
     // device image: [Q^T | G^T | m0] (one workgroup per particle, kernels/propagate.hip)
     if (int rc = image(3, 2 * dd + d, [&](std::vector<double> &img) {

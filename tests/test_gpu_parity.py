@@ -477,7 +477,7 @@ def test_draws_match_oracle(cs, oracle, d, dist, nu):
     D.close()
 
 
-@pytest.mark.parametrize("d", [2, 8, 16, 17, 32, 40, 48, 64, 65, 80, 96, 100, 113, 128])
+@pytest.mark.parametrize("d", [2, 8, 16, 17, 32, 40, 48, 64, 65, 80, 96, 100, 113, 128, 129, 144, 150, 192, 201, 256])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0)])
 def test_propagate_matches_oracle(cs, oracle, d, dist, nu):
     """propagate_K (src/mcmc.cpp:112-140): gather by ancestor + G x + Q xi, device-resident, against the
@@ -545,7 +545,7 @@ def test_propagate_diagonal_models(cs, oracle, d, dist, nu):
     assert np.allclose(init.cpu().numpy(), want0, rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("d", [16, 24, 64, 100, 128])
+@pytest.mark.parametrize("d", [16, 24, 64, 100, 128, 131, 160, 256])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0)])
 def test_propagate_diagonal_G_dense_Q(cs, oracle, d, dist, nu):
     """A diagonal G (random walk / AR(1) per component) under a dense Q: the matrix-core kernel runs
