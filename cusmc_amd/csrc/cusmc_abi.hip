@@ -771,7 +771,8 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
                                          count, X_out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
-  if (cusmc::propagate_mfma_wide_supported(d, X_prev_dev, X_out_dev)) {
+  // (CUSMC_PROPAGATE_ROWS=1: round 1's one-workgroup-per-particle kernel instead, for A/B timing)
+  if (cusmc::propagate_mfma_wide_supported(d, X_prev_dev, X_out_dev) && !getenv("CUSMC_PROPAGATE_ROWS")) {
     // 128 < d <= 256: matrix cores with the output blocks split over the waves (kernels/propagate_mfma_wide.hip).
     // device image: [frags(Q) | frags(G) or diag(G) or m0], factors zero-padded to 16*ceil(d/16)
     const int nb = (d + 15) / 16, dp = 16 * nb;

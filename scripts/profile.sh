@@ -11,10 +11,10 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-pmc --no-cpu"   # bench.py defaults: the same command the judged number comes from
+ARGS="--gpus 1 --steps 20 --warmup 5 --no-pmc --no-cpu"   # the driver's command (BENCH_rNN.json: `python3 bench.py --gpus 1 --steps 20 --warmup 5`)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$R/bench.py" $ARGS > "$OUT/kt.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" --no-pmc --no-cpu --steps 5 --warmup 2 > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" --no-pmc --no-cpu --steps 5 --warmup 2 > "$OUT/write.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" --gpus 1 --no-pmc --no-cpu --steps 5 --warmup 2 > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" --gpus 1 --no-pmc --no-cpu --steps 5 --warmup 2 > "$OUT/write.log" 2>&1
 # (4) the other BASELINE configs' kernels (resampler, wide kernel, fused filter step, proposal draws)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/configs" -- python3 "$R/scripts/bench_configs.py" > "$OUT/configs.log" 2>&1
 # (5), (6) matrix-core utilisation and LDS bank conflicts of every MFMA kernel

@@ -13,13 +13,27 @@ def short(n):
 def main(d):
     print("# rocprofv3 summary (%s)\n" % d.rstrip("/").split("/")[-1])
     for f in glob.glob(d + "/kt/**/*kernel_stats.csv", recursive=True):
-        print("## --kernel-trace --stats (python3 bench.py --no-pmc --no-cpu: default steps/warmup)\n")
+        print("## --kernel-trace --stats (python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-pmc --no-cpu: the driver's command)\n")
         print("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
         for r in csv.DictReader(open(f)):
             if float(r["Percentage"]) < 0.05:
                 continue
             print("| %s | %s | %.1f | %.1f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                            float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    # the 20 TIMED dispatches themselves: bench.py runs 595 settle + 5 warm-up launches of the headline kernel,
+    # then the timed 20 (then the strong-scaling leg's 800); rocprof's duration excludes the ~2.5 us between launches
+    for f in glob.glob(d + "/kt/**/*kernel_trace.csv", recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if "logpdf_mfma_kernel<4, true, false, 0, 1, false>" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        if len(rows) >= 620:
+            win = rows[600:620]
+            dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in win]
+            span = (int(win[-1]["End_Timestamp"]) - int(win[0]["Start_Timestamp"])) / 1e3 / len(win)
+            print("\nThe 20 timed dispatches (#601-620 of the headline kernel): kernel duration avg %.2f us (min %.2f, max %.2f); "
+                  "start-to-end span / 20 = %.2f us per launch including the gaps between launches -- the quantity "
+                  "bench.py's HIP events measure (`roofline.kernel_ms`)." % (sum(dur) / len(dur), min(dur), max(dur), span))
+            alld = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+            print("All %d dispatches of that kernel in the run: avg %.2f us." % (len(alld), sum(alld) / len(alld)))
     for f in glob.glob(d + "/configs/**/*kernel_stats.csv", recursive=True):
         print("\n## --kernel-trace --stats (python3 scripts/bench_configs.py: the other BASELINE configs)\n")
         print("| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|")
