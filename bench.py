@@ -44,6 +44,7 @@ EXPECTED_KERNEL = "cusmc::logpdf_mfma_kernel<4, true, false, 0, 1, false>"
 C5_N, C5_D = 4_000_000, 256      # BASELINE configs[4]: d=256 MVN, 4e6 particles over the node
 F64_MFMA_PEAK_TFLOPS = 78.6      # public spec; measured 77.7 (profiles/r01_calibration.txt)
 PF_N = 1_000_000                 # BASELINE configs[2]: particle filter, 1e6 particles
+AUX_TIMEOUT_S = 300              # rank 0 prints the headline line by itself if the legs after it hang this long
 
 
 def make_sigma(d, seed):
@@ -256,6 +257,99 @@ def main():
     # like the headline: every rank owns MH_N chains of a world x MH_N vector; the one real exchange
     # step of this path -- the all-gather of the weight shards (cusmc_amd/sharding.py) -- is inside
     # the timed loop.  A failure here must not cost the headline line: it is reported in "mh".
+    # ---- the line: everything the contract asks for is known here; the legs below only add to it --------------
+    line = None
+    if rank == 0:
+        evals = world * N_PER_GPU * args.steps
+        achieved = N_PER_GPU * ALGO_BYTES_PER_EVAL / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "MVN log-pdf evals/sec (1e6 particles, d=64)",
+            "value": evals / wall_max,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "clock_settle_launches": settle,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one device, gloo)",
+            "config": {"workload": "mvn_logpdf fp64: N=%d particles per GPU x d=%d, Sigma = AA^T/d + I "
+                                   "(seed 1), device-resident, one launch per step" % (N_PER_GPU, D),
+                       "particles_per_gpu": N_PER_GPU, "d": D, "parallelism": "particle-sharded x%d, "
+                       "no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if traffic is None else traffic["hbm_bytes"],
+                         "algorithmic_bytes_per_launch": N_PER_GPU * ALGO_BYTES_PER_EVAL,
+                         # the name the PMC pass matched; without that pass, the instantiation this
+                         # workload dispatches to (logpdf_mfma.hip: NB = 4, centred, no shift, MVN epilogue)
+                         "kernel": traffic["kernel"] if traffic else EXPECTED_KERNEL,
+                         "kernel_name_source": "rocprofv3 counter_collection.csv" if traffic else "expected (no PMC pass)",
+                         "kernel_ms": kernel_ms,
+                         "frac_of_measured_copy_peak": achieved / 6290.0},
+            "cpu_baseline": None,
+            "mh_steps_per_s": None,
+            "mh": None,
+            "strong": None,
+            "filter_step": None,
+            "ranks": world if world == 1 else int(dist.get_world_size()),
+            "backend": "single process" if world == 1 else dist.get_backend(),
+            "parity_max_rel_err_vs_oracle": None,
+        }
+        if traffic is not None:
+            line["roofline"]["traffic_detail"] = {k: v for k, v in traffic.items() if k != "kernel"}
+    emitted = []
+
+    def emit():
+        if rank == 0 and not emitted:
+            emitted.append(True)
+            print(json.dumps(line), flush=True)
+
+    # The legs below run collectives on N > 1 ranks.  Whatever happens in them must not cost the headline
+    # line: on one rank an exception is recorded in the line; on several, a rank that threw can no longer keep
+    # step with its peers' collectives, so it reports (rank 0: prints the line with the error) and leaves the
+    # job at once, and a watchdog on rank 0 prints the line if its peers never come back.
+    watchdog = None
+    if world > 1 and rank == 0:
+        import threading
+
+        def _late():
+            line["aux_error"] = "auxiliary legs did not finish within %d s: headline reported without them" % AUX_TIMEOUT_S
+            emit()
+            os._exit(0)
+        watchdog = threading.Timer(AUX_TIMEOUT_S, _late)
+        watchdog.daemon = True
+        watchdog.start()
+
+    def aux_failed(name, exc):
+        import traceback
+        sys.stderr.write("bench: leg '%s' failed on rank %d:\n%s\n" % (name, rank, traceback.format_exc()))
+        if world > 1:
+            if rank == 0:
+                line[name] = {"error": repr(exc)}
+                line["aux_error"] = "leg '%s' failed; later legs not run" % name
+                emit()
+            sys.stderr.flush()
+            os._exit(0)
+        return {"error": repr(exc)}
+
+    def timed_max(fn, reps, warm=3):
+        """seconds per repetition of fn(), barrier + synchronize on both sides, MAX over ranks"""
+        for _ in range(warm):
+            fn()
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        tt = torch.tensor([(time.perf_counter() - t_) / reps], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     mh = None
     try:
         from cusmc_amd import sharding
@@ -295,23 +389,7 @@ def main():
                           % (world, MH_N, MH_B, MH_D, "" if world == 1 else "; all-gather of the weight shards timed")}
         d32.close()
     except Exception as exc:  # noqa: BLE001
-        if world > 1:
-            raise
-        mh = {"steps_per_s": None, "error": repr(exc)}
-
-    def timed_max(fn, reps, warm=3):
-        """seconds per repetition of fn(), barrier + synchronize on both sides, MAX over ranks"""
-        for _ in range(warm):
-            fn()
-        barrier()
-        t_ = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        barrier()
-        tt = torch.tensor([(time.perf_counter() - t_) / reps], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
+        mh = aux_failed("mh", exc)
 
     # Strong scaling (fixed TOTAL work split over the ranks, no data-path collective): the headline's
     # 1e6 x 64 batch, and BASELINE configs[4]'s 4e6 x 256 (MFMA-bound: reported against the f64 matrix peak).
@@ -340,9 +418,7 @@ def main():
         d256.close()
         del X5, out5
     except Exception as exc:  # noqa: BLE001
-        if world > 1:
-            raise  # a rank that skips ahead would pair its next collective with its peers' current one
-        strong = {"error": repr(exc), "partial": strong}
+        strong = aux_failed("strong", exc)
 
     # One bootstrap-filter time step with the particles sharded (BASELINE configs[2]: 1e6 particles in all):
     # all-gather of w_{t-1}, resample, all-to-all of the ancestor rows, propagate, reweight -- both
@@ -371,9 +447,7 @@ def main():
             obs.close()
             obs2.close()
     except Exception as exc:  # noqa: BLE001
-        if world > 1:
-            raise
-        filt = {"error": repr(exc), "partial": filt}
+        filt = aux_failed("filter_step", exc)
 
     # The CPU leg is the only place bench.py touches oracle/: it times the reference-faithful port
     # and, while it has it loaded, checks the sample of the GPU's outputs against it.
@@ -384,51 +458,14 @@ def main():
         want = O.logpdf_hoisted(sample_in, mu, sigma)
         parity = float(np.max(np.abs(sample_out - want) / np.abs(want)))
 
+    if rank == 0:
+        line.update({"cpu_baseline": cpu, "mh_steps_per_s": None if not mh else mh.get("steps_per_s"), "mh": mh,
+                     "strong": strong, "filter_step": filt, "parity_max_rel_err_vs_oracle": parity})
+        emit()
     if world > 1:
         dist.barrier()
-    if rank == 0:
-        evals = world * N_PER_GPU * args.steps
-        achieved = N_PER_GPU * ALGO_BYTES_PER_EVAL / (kernel_ms * 1e-3) / 1e9
-        line = {
-            "metric": "MVN log-pdf evals/sec (1e6 particles, d=64)",
-            "value": evals / wall_max,
-            "unit": "evals/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "clock_settle_launches": settle,
-            "ms_per_step": wall_max / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one device, gloo)",
-            "config": {"workload": "mvn_logpdf fp64: N=%d particles per GPU x d=%d, Sigma = AA^T/d + I "
-                                   "(seed 1), device-resident, one launch per step" % (N_PER_GPU, D),
-                       "particles_per_gpu": N_PER_GPU, "d": D, "parallelism": "particle-sharded x%d, "
-                       "no data-path collective" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if traffic is None else traffic["hbm_bytes"],
-                         "algorithmic_bytes_per_launch": N_PER_GPU * ALGO_BYTES_PER_EVAL,
-                         # the name the PMC pass matched; without that pass, the instantiation this
-                         # workload dispatches to (logpdf_mfma.hip: NB = 4, centred, no shift, MVN epilogue)
-                         "kernel": traffic["kernel"] if traffic else EXPECTED_KERNEL,
-                         "kernel_name_source": "rocprofv3 counter_collection.csv" if traffic else "expected (no PMC pass)",
-                         "kernel_ms": kernel_ms,
-                         "frac_of_measured_copy_peak": achieved / 6290.0},
-            "cpu_baseline": cpu,
-            "mh_steps_per_s": None if mh is None else mh.get("steps_per_s"),
-            "mh": mh,
-            "strong": strong,
-            "filter_step": filt,
-            "ranks": world if world == 1 else int(dist.get_world_size()),
-            "backend": "single process" if world == 1 else dist.get_backend(),
-            "parity_max_rel_err_vs_oracle": parity,
-        }
-        if traffic is not None:
-            line["roofline"]["traffic_detail"] = {k: v for k, v in traffic.items() if k != "kernel"}
-        print(json.dumps(line), flush=True)
+    if watchdog is not None:
+        watchdog.cancel()
     mvn.close()
     if world > 1:
         dist.destroy_process_group()

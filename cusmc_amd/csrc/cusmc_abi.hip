@@ -1172,7 +1172,12 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   // cross PCIe than to compute): an event after the last step of each chunk, a second stream for
   // the copies.  Small histories are one chunk.
   const size_t step_bytes = slice * 8 + (size_t)N * 12;
-  const uint32_t chunk_steps = (size_t)T * step_bytes <= (128u << 20) ? T : (uint32_t)std::max<size_t>(1, (128u << 20) / step_bytes);
+  size_t chunk_bytes = 128u << 20;
+  if (const char *env = getenv("CUSMC_PF_CHUNK_BYTES")) {  // (test switch: lets a small filter take the chunked path)
+    const long long v = atoll(env);
+    if (v > 0) chunk_bytes = (size_t)v;
+  }
+  const uint32_t chunk_steps = (size_t)T * step_bytes <= chunk_bytes ? T : (uint32_t)std::max<size_t>(1, chunk_bytes / step_bytes);
   const uint32_t nchunks = (T + chunk_steps - 1) / chunk_steps;
   std::vector<hipEvent_t> chunk_done(nchunks, nullptr);
   hipStream_t copy_stream = nullptr;

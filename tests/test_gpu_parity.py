@@ -978,6 +978,27 @@ def test_multi_device_run_below_the_abi_equals_one_device(cs, N, d, T, dist, nu,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [1, 300_000, 5_000_000])
+def test_run_chunked_copy_out_equals_single_chunk(cs, monkeypatch, chunk):
+    """cusmc_pf_run_host streams a history above 128 MB back in chunks of whole time steps on a second
+    stream (per-chunk events, pre-faulting workers).  CUSMC_PF_CHUNK_BYTES forces that path on a small filter:
+    one step per chunk, a few steps per chunk, and a ragged last chunk must all return the single-chunk history.
+    (The 2.8 GB history of test_config2_filter_1e6_particles_T100 takes the same path at its natural size.)"""
+    N, d, T = 6007, 4, 13
+    rng = np.random.default_rng(9)
+    Y = np.cumsum(0.1 * rng.standard_normal((d, T)), axis=1)
+    I = np.eye(d)
+    args = (N, d, T, Y, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn")
+    one = cs.run(*args, seed=3, return_ancestors=True)
+    monkeypatch.setenv("CUSMC_PF_CHUNK_BYTES", str(chunk))
+    many = cs.run(*args, seed=3, return_ancestors=True)
+    for k in ("ancestors", "posterior_x", "weights"):
+        assert np.array_equal(one[k], many[k]), k
+    partial = cs.run(*args, seed=3)  # (no ancestors requested: a NULL output pointer on the chunked path)
+    assert np.array_equal(partial["posterior_x"], one["posterior_x"]) and np.array_equal(partial["weights"], one["weights"])
+
+
+@pytest.mark.gpu
 def test_cusmc_devices_environment_shards_run(cs, monkeypatch):
     """CUSMC_DEVICES in the environment routes the plain entry point (what rcpp/src/run.rcpp.cpp calls)
     through the multi-device loop; malformed lists are refused."""
