@@ -22,7 +22,9 @@
 //             sqrt(nu / chi2) per component (src/statistics.cc.cpp:385-386, 411; chi_square_batch, smallops.h),
 //             + G x (second accumulator), + g .* x (diagonal G) or + m0, stored 8 bytes per lane.
 // Two barriers per group.  The fill (RNG: VALU) and the multiply (MFMA) of one workgroup do not overlap;
-// an f64 MFMA blocks VALU issue on its SIMD anyway.  Algorithmic bytes per particle
+// an f64 MFMA blocks VALU issue on its SIMD anyway.  (Tried: the next group's ancestor
+// rows fetched during the current multiply, held in 16 VGPRs -- no gain for the Normal kernel, 3163 -> 3244 us
+// at 5e5 x 256 on another box, and the Student-t one spills: 4857 -> 5235 us.)  Algorithmic bytes per particle
 // 16 d + 4; flops 2 x 2 x (16 NB)^2 (dense G) -- MFMA-bound: 1.7 ms for 5e5 x 256 at the 77.7 TF peak.
 //
 // d that is not a multiple of 16 runs with the factors zero-padded to 16 NB on the host (PAD): normals
@@ -106,9 +108,12 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
 #pragma unroll
       for (int t = 0; t < T; ++t) accQ[b][t] = accG[b][t] = v4d{0.0, 0.0, 0.0, 0.0};
     auto product = [&](const double *__restrict__ frags, const double *sB, v4d(&acc)[2][T]) {
-      // fragment (kb, s, cb) is at ((kb 4 + s) NB + cb) x 64; the next k-block's eight values are requested
-      // before the current one's MFMAs are issued
-      double wc[4][2], wn[4][2];
+      // fragment (kb, s, cb) is at ((kb 4 + s) NB + cb) x 64.  Both operands of k-block kb + 1 -- eight fragment
+      // values from L2, four 16-byte pieces from LDS -- are requested before the MFMAs of k-block kb are issued;
+      // two register sets swap roles (loop unrolled by two: no copies).  -5 % (d = 256) to -7 % (d = 192)
+      // against fetching the LDS pieces at their use.
+      double wa[4][2], wb[4][2];
+      v2d xa[2][T], xb[2][T];
       auto load_w = [&](int kb, double(&dst)[4][2]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -116,30 +121,35 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
           dst[s][1] = two ? frags[(size_t)((kb * 4 + s) * NB + cb1) * 64 + lane] : 0.0;
         }
       };
-      load_w(0, wc);
-#pragma unroll 1  // (a rolled loop: unrolled, odd NB spill 70-256 VGPRs; the eight register copies per k-block are
-                  // nothing beside its 16 MFMAs)
-      for (int kb = 0; kb < NB; ++kb) {
-        if (kb + 1 < NB) load_w(kb + 1, wn);
-        v2d x[2][T];
+      auto load_x = [&](int kb, v2d(&dst)[2][T]) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-          for (int t = 0; t < T; ++t) x[h2][t] = reinterpret_cast<const v2d *>(sB + ((kb * 2 + h2) * T + t) * 128)[lane];
+          for (int t = 0; t < T; ++t) dst[h2][t] = reinterpret_cast<const v2d *>(sB + ((kb * 2 + h2) * T + t) * 128)[lane];
+      };
+      auto kblock = [&](int kb, double(&wc)[4][2], v2d(&xc)[2][T], double(&wn)[4][2], v2d(&xn)[2][T]) {
+        if (kb + 1 < NB) {
+          load_w(kb + 1, wn);
+          load_x(kb + 1, xn);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            const double bv = x[s >> 1][t][s & 1];
+            const double bv = xc[s >> 1][t][s & 1];
             acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][0], bv, acc[0][t], 0, 0, 0);
             if (two) acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][1], bv, acc[1][t], 0, 0, 0);
           }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          wc[s][0] = wn[s][0];
-          wc[s][1] = wn[s][1];
-        }
+      };
+      load_w(0, wa);
+      load_x(0, xa);
+      int kb = 0;
+#pragma unroll 1
+      for (; kb + 1 < NB; kb += 2) {
+        kblock(kb, wa, xa, wb, xb);
+        kblock(kb + 1, wb, xb, wa, xa);
       }
+      if (kb < NB) kblock(kb, wa, xa, wb, xb);
     };
     product(fragsQ, sXi, accQ);
     if constexpr (HAS_G) product(tail, sXg, MVT ? accG : accQ);  // (Normal: one accumulator takes both products)
