@@ -187,5 +187,24 @@ inline void particle_filter(double *post_x_t, double *w_t, unsigned *a_t, const 
                           seed, post_x_t, w_t, a_t));
 }
 
+// The same filter with the particles sharded over several GPUs of the node (cusmc_pf_run_multi_host: one host
+// thread + context per device, peer access; the loop being sharded is src/mcmc.cpp:292-308).  A device may be
+// listed more than once.  Same numbers as particle_filter().
+inline void particle_filter_multi(const std::vector<int> &devices, double *post_x_t, double *w_t, unsigned *a_t,
+                                  const double *y_t, const Matrix &F, const Matrix &G, const Vector &m0,
+                                  const Matrix &C0, const Matrix &sigmaV, const Matrix &sigmaW, dim_t N, dim_t d,
+                                  dim_t timeSteps, float df, const std::string &resampler_opt,
+                                  const std::string &distribution_opt, uint64_t seed = 0, unsigned B = 10)
+{
+  check(cusmc_pf_run_multi_host(devices.data(), (int)devices.size(), y_t, N, (int)d, timeSteps, m0.data(),
+                                C0.row_major().data(), F.row_major().data(), G.row_major().data(),
+                                sigmaV.row_major().data(), sigmaW.row_major().data(), df, resampler_opt.c_str(),
+                                distribution_opt.c_str(), B, 1.0, seed, post_x_t, w_t, a_t));
+}
+
+// Philox key of the `call`-th unseeded call of a session (the reference reseeds from std::random_device per call:
+// src/samplers.cpp:10-11); pass it as the `seed` of the functions above.
+inline uint64_t stream_key(uint64_t seed, uint64_t call) { return cusmc_stream_key(seed, call); }
+
 }  // namespace cusmc
 #endif

@@ -74,6 +74,13 @@ int main()
       try { particle_filter(X.data(), w.data(), a.data(), y.data(), I, I, Vector{0, 0}, I, I, I, N, d, T, 0.f, "systematic", "mvn"); }
       catch (const Error &e) { threw = e.code == CUSMC_EINVAL; }
       EXPECT(threw);
+      // three shards rehearsed on device 0: the sharded loop returns the same history bit for bit
+      std::vector<double> X2(T * N * d), w2(T * N);
+      std::vector<unsigned> a2(T * N);
+      particle_filter_multi({0, 0, 0}, X2.data(), w2.data(), a2.data(), y.data(), I, I, Vector{0, 0}, I, I, I, N, d, T, 0.f,
+                            "metropolis", "mvn", 7);
+      EXPECT(X2 == X && w2 == w && a2 == a);
+      EXPECT(stream_key(0, 0) == 0xE220A8397B1DCDAFull && stream_key(1, 0) != stream_key(1, 1));
     }
   } catch (const std::exception &e) {
     std::printf("FAIL exception: %s\n", e.what());
