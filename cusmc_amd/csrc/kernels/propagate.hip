@@ -92,7 +92,7 @@ __global__ __launch_bounds__(T) void propagate_kernel(
 // per (particle, component pair), i.e. per Philox block, consecutive lanes on consecutive pairs of
 // one row (16-byte segments, fully coalesced), any d.  Same operations as the general kernels
 // (fma(q, xi, 0) is the only non-zero term of their sum), hence the same values.
-template <bool MVT>
+template <bool MVT, int PPL = 4>  // PPL: pairs a lane takes at a time (Student-t)
 __global__ __launch_bounds__(256) void propagate_diag_kernel(
     float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
     const double *__restrict__ gdiag, const double *__restrict__ qdiag, const double *__restrict__ m0,
@@ -110,22 +110,54 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
   for (uint32_t il = blockIdx.x * rows_per_block + lane_row; il < count; il += gridDim.x * rows_per_block) {
     const uint32_t i = first + il;
     const long anc = gdiag ? (a ? (long)a[il] : (long)i) : 0;
-    for (int pr = lane_pr; pr < pairs; pr += pw) {
-      double z[2];
-      normal_pair(philox4x32_10(i, (uint32_t)pr, step, domain, k0, k1), z[0], z[1]);
-      double chi[2] = {1.0, 1.0};
-      if (MVT)  // the pair's two chi^2 draws together (smallops.h: chi_square_batch)
-        chi_square_batch<2>(cs, i, step, k0, k1, [&](int c) { return 2 * pr + c; }, [&](int c) { return 2 * pr + c < d; }, chi);
+    if constexpr (!MVT) {
+      for (int pr = lane_pr; pr < pairs; pr += pw) {
+        double z[2];
+        normal_pair(philox4x32_10(i, (uint32_t)pr, step, domain, k0, k1), z[0], z[1]);
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int j = 2 * pr + c;
-        if (j < d) {
-          const double xi = scale * z[c];
-          double s = fma(qdiag[j], xi, 0.0);
-          if (MVT) s = fma(s, sqrt((double)nu / chi[c]), 0.0);  // (an fma, so that no kernel contracts it with the add below)
-          const double m = gdiag ? fma(gdiag[j], X_prev[anc * d + j], 0.0) : m0[j];
-          X_out[(long)il * d + j] = s + m;
+        for (int c = 0; c < 2; ++c) {
+          const int j = 2 * pr + c;
+          if (j < d) {
+            const double s = fma(qdiag[j], scale * z[c], 0.0);
+            const double m = gdiag ? fma(gdiag[j], X_prev[anc * d + j], 0.0) : m0[j];
+            X_out[(long)il * d + j] = s + m;
+          }
         }
+      }
+    } else {
+      // Student-t: a lane takes PPL = 4 pairs of its row at a time (the launcher gives a row a quarter of the
+      // lanes; 1 below d = 7), so that their eight chi^2 draws go through chi_square_batch together -- with two
+      // draws per batch the wave pays the slow path of nearly every batch (smallops.h): 1400 -> 1165 us for
+      // 1e6 x 64; the pairs' values, same operations as above
+      for (int pr0 = lane_pr; pr0 < pairs; pr0 += PPL * pw) {
+        double z[PPL][2];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) z[q][0] = z[q][1] = 0.0;
+#pragma unroll 1
+        for (int q = 0; q < PPL; ++q) {
+          double z0 = 0.0, z1 = 0.0;
+          if (pr0 + q * pw < pairs) normal_pair(philox4x32_10(i, (uint32_t)(pr0 + q * pw), step, domain, k0, k1), z0, z1);
+#pragma unroll
+          for (int qq = 0; qq < PPL; ++qq) {
+            z[qq][0] = qq == q ? z0 : z[qq][0];
+            z[qq][1] = qq == q ? z1 : z[qq][1];
+          }
+        }
+        double chi[2 * PPL];
+        chi_square_batch<2 * PPL>(cs, i, step, k0, k1, [&](int c) { return 2 * (pr0 + (c >> 1) * pw) + (c & 1); },
+                            [&](int c) { return 2 * (pr0 + (c >> 1) * pw) + (c & 1) < d; }, chi);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int j = 2 * (pr0 + q * pw) + c;
+            if (j < d) {
+              double s = fma(qdiag[j], scale * z[q][c], 0.0);
+              s = fma(s, sqrt((double)nu / chi[2 * q + c]), 0.0);  // (an fma, so that no kernel contracts it with the add below)
+              const double m = gdiag ? fma(gdiag[j], X_prev[anc * d + j], 0.0) : m0[j];
+              X_out[(long)il * d + j] = s + m;
+            }
+          }
       }
     }
   }
@@ -141,11 +173,13 @@ hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const
   const int pairs = (d + 1) / 2;
   int pw_log2 = 0;
   while ((1 << pw_log2) < pairs && pw_log2 < 8) ++pw_log2;
+  const bool four = kind == CUSMC_MVT && pairs >= 4;
+  if (four) pw_log2 -= 2;  // four pairs per lane: eight chi^2 draws per batch
   const long rows_per_block = 256 >> pw_log2;
   long blocks = ((long)count + rows_per_block - 1) / rows_per_block;
   const long cap = (long)num_cus * 8;
   if (blocks > cap) blocks = cap;
-  auto kern = kind == CUSMC_MVT ? propagate_diag_kernel<true> : propagate_diag_kernel<false>;
+  auto kern = kind != CUSMC_MVT ? propagate_diag_kernel<false> : four ? propagate_diag_kernel<true, 4> : propagate_diag_kernel<true, 1>;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, nu, X_prev, a, gdiag, qdiag, m0, d,
                      pw_log2, scale, (uint32_t)seed, (uint32_t)(seed >> 32), step, domain, first, count, X_out);
   return hipGetLastError();
