@@ -19,7 +19,8 @@ def spd(d, seed):
 
 ctx = cusmc_amd.api.default_context().use_torch_stream()
 g = torch.Generator(device="cuda").manual_seed(7)
-for N, d in ((1_000_000, 64), (1_000_000, 32), (1_000_000, 128), (500_000, 192), (500_000, 256)):
+for N, d in ((1_000_000, 64), (1_000_000, 32), (1_000_000, 128), (500_000, 192), (500_000, 208), (500_000, 224), (500_000, 240),
+             (500_000, 256)):  # (the wide kernel at every block count it serves: NB = 12 .. 16)
     X = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
     out = torch.empty(N, dtype=torch.float64, device="cuda")
     D = cusmc_amd.MultiVariateNormalDistribution(np.zeros(d), spd(d, 1), ctx=ctx)
@@ -42,3 +43,17 @@ for i in range(5):
     cusmc_amd.api.propagate_dev(Xp, anc, 0.9 * np.eye(d) + 0.01 * Q, Q, out, "mvn", 0.0, 1.0, seed=1, step=i + 1, ctx=ctx)
     cusmc_amd.api.propagate_dev(Xp, anc, 0.9 * np.eye(d), Q, out, "mvn", 0.0, 1.0, seed=1, step=i + 1, ctx=ctx)
 torch.cuda.synchronize()
+# the wide proposal kernel (128 < d <= 256): dense and diagonal G, Normal and Student-t
+for N, d in ((250_000, 256), (250_000, 192), (250_000, 144)):
+    rng = np.random.default_rng(d)
+    Xp = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+    anc = torch.randint(0, N, (N,), dtype=torch.int32, device="cuda", generator=g)
+    out = torch.empty(N, d, dtype=torch.float64, device="cuda")
+    Gm = 0.9 * np.eye(d) + 0.1 * rng.standard_normal((d, d)) / np.sqrt(d)
+    Q = 0.3 * np.eye(d) + 0.1 * rng.standard_normal((d, d)) / np.sqrt(d)
+    for i in range(3):
+        for kind, nu in (("mvn", 0.0), ("mvt", 4.0)):
+            cusmc_amd.api.propagate_dev(Xp, anc, Gm, Q, out, kind, nu, 1.0, seed=1, step=i + 1, ctx=ctx)
+            cusmc_amd.api.propagate_dev(Xp, anc, np.diag(np.diag(Gm)), Q, out, kind, nu, 1.0, seed=1, step=i + 1, ctx=ctx)
+    torch.cuda.synchronize()
+    del Xp, anc, out
