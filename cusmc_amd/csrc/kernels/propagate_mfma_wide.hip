@@ -7,28 +7,34 @@
 // (src/mvn_dist.cu.cpp:33-172; mvt twins src/mvt_dist.cu.cpp:84-223).
 //
 // The factors (512 KB each at d = 256) fit neither LDS nor registers, so -- as in logpdf_mfma_wide.hip --
-// the OUTPUT dimension is split over the eight waves of a workgroup and the B operands of a group of 32
-// particles (two 16-particle tiles) are staged once in LDS for all of them:
-//   fill      every wave fills 1/8 of the group's operand slabs.  Slab (kb, h2, t) holds, for lane (p, h),
-//             the operands of k-steps 2 h2 and 2 h2 + 1 of k-block kb for particle 16 t + p: columns
-//             16 kb + 8 h2 + 2 h and + 1 -- exactly ONE Box-Muller pair (Philox block sub = 8 kb + 4 h2 + h:
-//             the RNG contract keys a block by component pair), resp. one 16-byte piece of the ancestor's
-//             row.  A lane writes its 16 bytes at slab + 16 lane; a compute wave reads a slab back with
-//             one conflict-free ds_read_b128 per lane.
-//   multiply  wave w owns output blocks w and w + 8 for both tiles; the A fragments of its blocks stream
-//             from L2 (mfma_pack_frags order, 512 contiguous bytes per fragment) one k-block ahead of
-//             their use: 2 blocks x 2 tiles x 4 NB MFMAs per factor per group and wave.
+// the OUTPUT dimension is split over the eight waves of a workgroup and the B operands of a group of 64
+// particles (four 16-particle tiles) are staged once in LDS for all of them:
+//   fill      slab (kb, h2, t) holds, for lane (p, h), the operands of k-steps 2 h2 and 2 h2 + 1 of k-block kb for
+//             particle 16 t + p: columns 16 kb + 8 h2 + 2 h and + 1 -- exactly ONE Box-Muller pair (Philox block
+//             sub = 8 kb + 4 h2 + h: the RNG contract keys a block by component pair), resp. one 16-byte piece of
+//             the ancestor's row.  Wave w fills tile w % 4, half w / 4 of every k-block; a lane writes its 16
+//             bytes at slab + 16 lane; a compute wave reads a slab back with one conflict-free ds_read_b128.
+//   multiply  wave w owns output blocks w and w + 8 for the four tiles; the A fragments of its blocks stream
+//             from L2 (mfma_pack_frags order, 512 contiguous bytes per fragment, buffer loads) one k-block ahead
+//             of their use, each feeding FOUR MFMAs: 2 blocks x 4 tiles x 4 NB MFMAs per factor, group and wave.
+//   the two products take TURNS on one set of slabs (128 KB at d = 256): normals -> Q Xi -> [Student-t: scale] ->
+//             gathered rows -> += G X.  Round 2's first version kept both operand sets in LDS at once, which
+//             capped a group at 32 particles: every fragment fed two MFMAs and the eight waves pulled 1 MB from
+//             L2 per group -- 16 GB per 5e5 x 256 launch, ~10 TB/s, which is what the launch took (ablation: 1.83
+//             ms with the MFMAs removed, 2.50 ms with the fill removed, against a 1.68 ms MFMA floor).  Four tiles
+//             halve that traffic.
 //   epilogue  lane (p, h), register r holds output dim 16 cb + h + 4 r of particle p: Student-t scaling by
 //             sqrt(nu / chi2) per component (src/statistics.cc.cpp:385-386, 411; chi_square_batch, smallops.h),
-//             + G x (second accumulator), + g .* x (diagonal G) or + m0, stored 8 bytes per lane.
-// Two barriers per group.  The fill (RNG: VALU) and the multiply (MFMA) of one workgroup do not overlap;
-// an f64 MFMA blocks VALU issue on its SIMD anyway.  (Tried: the next group's ancestor
-// rows fetched during the current multiply, held in 16 VGPRs -- no gain for the Normal kernel, 3163 -> 3244 us
-// at 5e5 x 256 on another box, and the Student-t one spills: 4857 -> 5235 us.)  Algorithmic bytes per particle
-// 16 d + 4; flops 2 x 2 x (16 NB)^2 (dense G) -- MFMA-bound: 1.7 ms for 5e5 x 256 at the 77.7 TF peak.
+//             + g .* x (diagonal G) or + m0, stored 8 bytes per lane.
+// Three barriers per group with a dense G (four for Student-t), two without.  The fill (RNG: VALU) and the multiply
+// (MFMA) of one workgroup do not overlap; an f64 MFMA blocks VALU issue on its SIMD anyway.
+// Algorithmic bytes per particle 16 d + 4; flops 2 x 2 x (16 NB)^2 (dense G) -- MFMA-bound: 1.7 ms for 5e5 x 256
+// at the 77.7 TF peak.
 //
 // d that is not a multiple of 16 runs with the factors zero-padded to 16 NB on the host (PAD): normals
 // for pairs past d are not drawn, gathered columns past d are zeroed, outputs past d are not stored.
+#include <type_traits>
+
 #include "smallops.h"
 
 namespace cusmc {
@@ -37,7 +43,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));  // rows are 8-byte aligned in general
 
-constexpr int kWideTiles = 2;          // 16-particle tiles per group
+constexpr int kWideTiles = 4;          // 16-particle tiles per group
 constexpr int kWideGroup = 16 * kWideTiles;
 
 bool propagate_mfma_wide_supported(int d, const void *X_prev, const void *X_out)
@@ -45,7 +51,12 @@ bool propagate_mfma_wide_supported(int d, const void *X_prev, const void *X_out)
   return d > 128 && d <= 256 && (uintptr_t)X_prev % 8 == 0 && (uintptr_t)X_out % 8 == 0;
 }
 
-size_t propagate_wide_lds_bytes(int nb, bool has_g) { return (size_t)nb * 2 * kWideTiles * 1024 * (has_g ? 2 : 1); }
+// one set of slabs (the two products take turns); the Student-t kernel also parks 8 waves x 16 KB of accumulators there
+size_t propagate_wide_lds_bytes(int nb, bool mvt)
+{
+  const size_t slabs = (size_t)nb * 2 * kWideTiles * 1024, park = 8 * 16384;
+  return mvt && park > slabs ? park : slabs;
+}
 
 // MODE 0: x = [diag(c)] Q xi + m0     (tail = m0, d doubles)
 //      1: x = [diag(c)] Q xi + G x_prev[a]   (tail = fragments of G)
@@ -58,11 +69,10 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
     long num_groups)
 {
   constexpr int T = kWideTiles;
+  static_assert(T == 4, "the fill below gives wave w tile w % 4, half (w / 4) & 1 and every k-block");
   constexpr bool HAS_G = MODE == 1;
-  constexpr int SLABS = NB * 2 * T;
   extern __shared__ double lds[];
-  double *sXi = lds;                 // SLABS x 128 doubles
-  double *sXg = lds + SLABS * 128;   // the same for the gathered rows (HAS_G)
+  double *sB = lds;  // NB x 2 x T slabs of 128 doubles: the normals, then (HAS_G) the gathered rows
 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -71,54 +81,73 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
   // this wave's output blocks: w, and w + 8 if there is one
   const int cb0 = w, cb1 = w + 8;
   const bool two = cb1 < NB;
+  // this wave's share of a fill: slabs w + 8 kb, kb = 0 .. NB - 1 -- tile ft, half fh2 of every k-block
+  const int ft = w & 3, fh2 = w >> 2;
 
   for (long g = blockIdx.x; g < num_groups; g += gridDim.x) {
     const long base = g * kWideGroup;  // first local row of the group
-    // ---- fill: this wave's share of the slabs ------------------------------------------------------
-    for (int sl = w; sl < SLABS; sl += 8) {
-      const int t = sl % T, h2 = (sl / T) & 1, kb = sl / (2 * T);  // (wave-uniform)
-      const long local = base + 16 * t + p;
-      const bool live = local < (long)count;
-      const uint32_t gi = first + (uint32_t)(live ? local : (long)count - 1);
-      const int col = 16 * kb + 8 * h2 + 2 * h;  // the pair's first column
+    const long flocal = base + 16 * ft + p;
+    const bool flive = flocal < (long)count;
+    const uint32_t fgi = first + (uint32_t)(flive ? flocal : (long)count - 1);
+    // ---- the ancestor's row.  Normal: requested first, its pieces travel while the normals are drawn and wait in
+    // 2 NB registers until the slabs are free.  Student-t: requested when the slabs are free (the chi-square
+    // constants on top of those registers would spill in the multiply; the exposed round trip is ~1.5 %) ----------
+    v2d xg[HAS_G ? NB : 1];
+    auto gather = [&]() {
+      const uint32_t anc = a ? a[flive ? flocal : (long)count - 1] : fgi;
+      const double *row = X_prev + (long)anc * d;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        const int col = 16 * kb + 8 * fh2 + 2 * h;
+        if (!PAD || col + 1 < d) {
+          xg[kb] = *reinterpret_cast<const v2d_a8 *>(row + col);
+        } else {
+          xg[kb] = v2d{col < d ? row[col] : 0.0, 0.0};
+        }
+      }
+    };
+    if constexpr (HAS_G && !MVT) gather();
+    // ---- fill: the normals ----------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int kb = 0; kb < NB; ++kb) {
+      const int col = 16 * kb + 8 * fh2 + 2 * h;  // the pair's first column
       double z0 = 0.0, z1 = 0.0;
       if (!PAD || col < d) {
-        normal_pair(philox4x32_10(gi, (uint32_t)(8 * kb + 4 * h2 + h), step, domain, k0, k1), z0, z1);
+        normal_pair(philox4x32_10(fgi, (uint32_t)(8 * kb + 4 * fh2 + h), step, domain, k0, k1), z0, z1);
         z0 *= scale;
         z1 = (!PAD || col + 1 < d) ? z1 * scale : 0.0;
       }
-      reinterpret_cast<v2d *>(sXi + sl * 128)[lane] = v2d{z0, z1};
-      if constexpr (HAS_G) {
-        const uint32_t anc = a ? a[live ? local : (long)count - 1] : gi;
-        const double *row = X_prev + (long)anc * d;
-        v2d x;
-        if (!PAD || col + 1 < d) {
-          x = *reinterpret_cast<const v2d_a8 *>(row + col);
-        } else {
-          x = v2d{col < d ? row[col] : 0.0, 0.0};
-        }
-        reinterpret_cast<v2d *>(sXg + sl * 128)[lane] = x;
-      }
+      reinterpret_cast<v2d *>(sB + (w + 8 * kb) * 128)[lane] = v2d{z0, z1};
     }
     __syncthreads();
-    // ---- multiply: blocks cb0 (and cb1) x both tiles -------------------------------------------------
-    v4d accQ[2][T], accG[2][T];
+    // ---- multiply: blocks cb0 (and cb1) x the four tiles ----------------------------------------------------
+    v4d acc[2][T];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int t = 0; t < T; ++t) accQ[b][t] = accG[b][t] = v4d{0.0, 0.0, 0.0, 0.0};
-    auto product = [&](const double *__restrict__ frags, const double *sB, v4d(&acc)[2][T]) {
+      for (int t = 0; t < T; ++t) acc[b][t] = v4d{0.0, 0.0, 0.0, 0.0};
+    // TWO (does this wave carry a second block) is a COMPILE-TIME property of the loop: as a run-time flag it put a
+    // branch around every second MFMA and every second fragment load, and hipcc's waitcnt pass, which must serve the
+    // path with the fewest loads in flight, then waited for the fragments of k-block kb + 1 before the MFMAs of
+    // k-block kb (vmcnt(7) .. vmcnt(0) with eight loads just issued): the prefetch distance was zero.
+    auto product = [&](auto two_tag, const double *__restrict__ frags) {
+      constexpr bool TWO = decltype(two_tag)::value;
       // fragment (kb, s, cb) is at ((kb 4 + s) NB + cb) x 64.  Both operands of k-block kb + 1 -- eight fragment
-      // values from L2, four 16-byte pieces from LDS -- are requested before the MFMAs of k-block kb are issued;
-      // two register sets swap roles (loop unrolled by two: no copies).  -5 % (d = 256) to -7 % (d = 192)
-      // against fetching the LDS pieces at their use.
+      // values from L2, eight 16-byte pieces from LDS -- are requested before the MFMAs of k-block kb are issued;
+      // two register sets swap roles (loop unrolled by two: no copies).
       double wa[4][2], wb[4][2];
       v2d xa[2][T], xb[2][T];
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(frags), 0, NB * 4 * NB * 512, 0x00020000);
+      const int lane8 = lane * 8;
       auto load_w = [&](int kb, double(&dst)[4][2]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          dst[s][0] = frags[(size_t)((kb * 4 + s) * NB + cb0) * 64 + lane];
-          dst[s][1] = two ? frags[(size_t)((kb * 4 + s) * NB + cb1) * 64 + lane] : 0.0;
+          // (buffer loads: SGPR descriptor + scalar fragment offset + one shared lane offset, instead of a 64-bit
+          // VGPR pointer per fragment -- a dozen such pointers were the difference between 256 VGPRs with spills
+          // and none)
+          const int off = ((kb * 4 + s) * NB + cb0) * 512;
+          dst[s][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, off, 0));
+          if constexpr (TWO) dst[s][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, off + 8 * 512, 0));
         }
       };
       auto load_x = [&](int kb, v2d(&dst)[2][T]) {
@@ -127,43 +156,104 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
 #pragma unroll
           for (int t = 0; t < T; ++t) dst[h2][t] = reinterpret_cast<const v2d *>(sB + ((kb * 2 + h2) * T + t) * 128)[lane];
       };
-      auto kblock = [&](int kb, double(&wc)[4][2], v2d(&xc)[2][T], double(&wn)[4][2], v2d(&xn)[2][T]) {
-        if (kb + 1 < NB) {
-          load_w(kb + 1, wn);
-          load_x(kb + 1, xn);
-        }
+      auto mfmas = [&](double(&wc)[4][2], v2d(&xc)[2][T]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             const double bv = xc[s >> 1][t][s & 1];
             acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][0], bv, acc[0][t], 0, 0, 0);
-            if (two) acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][1], bv, acc[1][t], 0, 0, 0);
+            if constexpr (TWO) acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][1], bv, acc[1][t], 0, 0, 0);
           }
       };
+      // The loop body requests UNCONDITIONALLY (the last one or two k-blocks are peeled off behind it): a branch
+      // around a request leaves the waitcnt pass two paths to serve, and it serves the one without the new loads --
+      // vmcnt(7) .. vmcnt(0) in front of MFMAs whose operands arrived a k-block ago, i.e. a wait for the loads
+      // just issued on every second k-block.
       load_w(0, wa);
       load_x(0, xa);
       int kb = 0;
 #pragma unroll 1
-      for (; kb + 1 < NB; kb += 2) {
-        kblock(kb, wa, xa, wb, xb);
-        kblock(kb + 1, wb, xb, wa, xa);
+      for (; kb + 2 < NB; kb += 2) {
+        load_w(kb + 1, wb);
+        load_x(kb + 1, xb);
+        mfmas(wa, xa);
+        load_w(kb + 2, wa);
+        load_x(kb + 2, xa);
+        mfmas(wb, xb);
       }
-      if (kb < NB) kblock(kb, wa, xa, wb, xb);
+      if constexpr (NB % 2 == 0) {
+        load_w(NB - 1, wb);
+        load_x(NB - 1, xb);
+        mfmas(wa, xa);
+        mfmas(wb, xb);
+      } else {
+        mfmas(wa, xa);
+      }
     };
-    product(fragsQ, sXi, accQ);
-    if constexpr (HAS_G) product(tail, sXg, MVT ? accG : accQ);  // (Normal: one accumulator takes both products)
+    auto multiply = [&](const double *__restrict__ frags) {
+      if constexpr (NB == 16) {
+        product(std::true_type{}, frags);
+      } else {
+        if (two) product(std::true_type{}, frags);
+        else product(std::false_type{}, frags);
+      }
+    };
+    multiply(fragsQ);
+    // lane (p, h), register r of block b holds output dim j = 16 cb_b + h + 4 r of particle p
+    auto jof = [&](int c) { return 16 * ((c >> 2) ? cb1 : cb0) + h + 4 * (c & 3); };
+    auto ok = [&](int c) { return ((c >> 2) == 0 || two) && (!PAD || jof(c) < d); };
+    if constexpr (MVT) {
+      // Student-t: Q xi scaled per component by sqrt(nu / chi2) BEFORE G x_prev is added on top.  A batch of draws
+      // wants ~150 registers; with the 64 accumulator registers live beside it hipcc spilled the accumulators to
+      // scratch and picked them out again piece by piece (~6 GB of scratch traffic per 5e5 x 256 launch).  The slabs
+      // are free at this point and are exactly 8 waves x 16 KB: each wave parks its accumulators in its own 16 KB,
+      // scales them there one tile per trip of a ROLLED loop (one copy of the batch in the instruction stream
+      // instead of four), and takes them back.
+      __syncthreads();  // every wave has read the normals
+      v2d *park = reinterpret_cast<v2d *>(sB + w * 2048) + lane;  // plane ((b T + t) 2 + i): registers 2 i, 2 i + 1
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          park[((b * T + t) * 2 + 0) * 64] = v2d{acc[b][t][0], acc[b][t][1]};
+          park[((b * T + t) * 2 + 1) * 64] = v2d{acc[b][t][2], acc[b][t][3]};
+        }
+#pragma unroll 1
+      for (int t = 0; t < T; ++t) {
+        const long local = base + 16 * t + p;
+        const uint32_t gi = first + (uint32_t)(local < (long)count ? local : (long)count - 1);
+        double chi[8];
+        chi_square_batch<8>(cs, gi, step, k0, k1, jof, ok, chi);
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+          v2d *q = park + (((c >> 2) * T + t) * 2 + ((c >> 1) & 1)) * 64;
+          const v2d v = *q;
+          *q = v2d{v[0] * sqrt((double)nu / chi[c]), v[1] * sqrt((double)nu / chi[c + 1])};
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const v2d lo = park[((b * T + t) * 2 + 0) * 64], hi = park[((b * T + t) * 2 + 1) * 64];
+          acc[b][t] = v4d{lo[0], lo[1], hi[0], hi[1]};
+        }
+    }
+    if constexpr (HAS_G) {
+      if constexpr (MVT) gather();
+      __syncthreads();  // every wave has read the normals: the slabs take the gathered rows
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) reinterpret_cast<v2d *>(sB + (w + 8 * kb) * 128)[lane] = xg[kb];
+      __syncthreads();
+      multiply(tail);
+    }
     // ---- epilogue ------------------------------------------------------------------------------------
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const long local = base + 16 * t + p;
       if (local >= (long)count) continue;
       const uint32_t gi = first + (uint32_t)local;
-      // the lane's eight components of this particle: c = 4 b + r  ->  j = 16 cb_b + h + 4 r
-      auto jof = [&](int c) { return 16 * ((c >> 2) ? cb1 : cb0) + h + 4 * (c & 3); };
-      auto ok = [&](int c) { return ((c >> 2) == 0 || two) && (!PAD || jof(c) < d); };
-      double chi[MVT ? 8 : 1];
-      if constexpr (MVT) chi_square_batch<8>(cs, gi, step, k0, k1, jof, ok, chi);
       const double *xrow = nullptr;
       if constexpr (MODE == 4) xrow = X_prev + (long)(a ? a[local] : gi) * d;
 #pragma unroll
@@ -173,11 +263,7 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * (b ? cb1 : cb0) + h + 4 * r;
           if (PAD && j >= d) continue;
-          double v = accQ[b][t][r];
-          if constexpr (MVT) {
-            v *= sqrt((double)nu / chi[4 * b + r]);
-            if (HAS_G) v += accG[b][t][r];
-          }
+          double v = acc[b][t][r];
           if constexpr (MODE == 0) v += tail[j];
           if constexpr (MODE == 4) v += fma(tail[j], xrow[j], 0.0);  // (the one non-zero term of the dense kernels' sum)
           X_out[local * d + j] = v;
@@ -193,7 +279,7 @@ static hipError_t launch_pw(float nu, const double *X_prev, const uint32_t *a, c
                             int d, double scale, uint64_t seed, uint32_t step, uint32_t domain, uint32_t first,
                             uint32_t count, double *X_out, int num_cus, hipStream_t stream)
 {
-  const size_t lds_bytes = propagate_wide_lds_bytes(NB, MODE == 1);
+  const size_t lds_bytes = propagate_wide_lds_bytes(NB, MVT);
   auto kern = propagate_wide_kernel<NB, MVT, MODE, PAD>;
   static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
