@@ -26,6 +26,8 @@
 
 namespace cusmc {
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+
 template <int T>
 __global__ __launch_bounds__(T) void propagate_kernel(
     int kind, float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
@@ -92,6 +94,10 @@ __global__ __launch_bounds__(T) void propagate_kernel(
 // per (particle, component pair), i.e. per Philox block, consecutive lanes on consecutive pairs of
 // one row (16-byte segments, fully coalesced), any d.  Same operations as the general kernels
 // (fma(q, xi, 0) is the only non-zero term of their sum), hence the same values.
+// rows a lane of the Normal kernel takes per trip (8: 325 us against 302 for 1e6 x 64; forcing 6 or 8 waves per SIMD
+// spills: 540 .. 830 us)
+constexpr int kDiagRows = 4;
+
 template <bool MVT, int PPL = 4>  // PPL: pairs a lane takes at a time (Student-t)
 __global__ __launch_bounds__(256) void propagate_diag_kernel(
     float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
@@ -107,24 +113,66 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
   const int lane_pr = (int)threadIdx.x & (pw - 1);
   const uint32_t lane_row = threadIdx.x >> pw_log2;
   const ChiSquare cs = chi_setup(MVT ? nu : 2.0f);
-  for (uint32_t il = blockIdx.x * rows_per_block + lane_row; il < count; il += gridDim.x * rows_per_block) {
-    const uint32_t i = first + il;
-    const long anc = gdiag ? (a ? (long)a[il] : (long)i) : 0;
-    if constexpr (!MVT) {
-      for (int pr = lane_pr; pr < pairs; pr += pw) {
-        double z[2];
-        normal_pair(philox4x32_10(i, (uint32_t)pr, step, domain, k0, k1), z[0], z[1]);
+  if constexpr (!MVT) {
+    // Normal: a lane takes its pair of U = 4 rows at a time -- the four ancestor indices, then the four 16-byte
+    // pieces of the ancestors' rows are requested before the first normal is drawn.  One row at a time, a CU's 32
+    // waves kept 32 KB in flight and the kernel ran at what that buys (3.8 TB/s of gather + store, RNG on top:
+    // 375 us for 1e6 x 64; 302 us now, which is the VALU time of the draws: ~1400 cycles per wave and pair);
+    // the values are the same operations as before.
+    constexpr int U = kDiagRows;
+    const uint32_t stride = gridDim.x * rows_per_block;
+    const bool wide = (d & 1) == 0 && (((uintptr_t)X_prev | (uintptr_t)X_out) & 15) == 0;  // 16-byte pieces
+    for (uint32_t il0 = blockIdx.x * rows_per_block + lane_row; il0 < count; il0 += U * stride) {
+      uint32_t il[U];
+      long anc[U];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int j = 2 * pr + c;
-          if (j < d) {
-            const double s = fma(qdiag[j], scale * z[c], 0.0);
-            const double m = gdiag ? fma(gdiag[j], X_prev[anc * d + j], 0.0) : m0[j];
-            X_out[(long)il * d + j] = s + m;
+      for (int u = 0; u < U; ++u) {
+        il[u] = il0 + u * stride;
+        const uint32_t ic = il[u] < count ? il[u] : count - 1;  // (clamped: loaded, never stored)
+        anc[u] = gdiag ? (a ? (long)a[ic] : (long)(first + ic)) : 0;
+      }
+      for (int pr = lane_pr; pr < pairs; pr += pw) {
+        const int j = 2 * pr;
+        const bool both = j + 1 < d;
+        double x[U][2];
+        if (gdiag) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const double *src = X_prev + anc[u] * d + j;
+            if (wide) {
+              const v2d v = *reinterpret_cast<const v2d *>(src);
+              x[u][0] = v[0], x[u][1] = v[1];
+            } else {
+              x[u][0] = src[0];
+              x[u][1] = both ? src[1] : 0.0;
+            }
+          }
+        }
+        const double q0 = qdiag[j], q1 = both ? qdiag[j + 1] : 0.0;
+        const double t0 = gdiag ? gdiag[j] : m0[j], t1 = both ? (gdiag ? gdiag[j + 1] : m0[j + 1]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (il[u] >= count) continue;
+          double z0, z1;
+          normal_pair(philox4x32_10(first + il[u], (uint32_t)pr, step, domain, k0, k1), z0, z1);
+          const double o0 = fma(q0, scale * z0, 0.0) + (gdiag ? fma(t0, x[u][0], 0.0) : t0);
+          const double o1 = fma(q1, scale * z1, 0.0) + (gdiag ? fma(t1, x[u][1], 0.0) : t1);
+          double *dst = X_out + (long)il[u] * d + j;
+          if (wide) {
+            *reinterpret_cast<v2d *>(dst) = v2d{o0, o1};
+          } else {
+            dst[0] = o0;
+            if (both) dst[1] = o1;
           }
         }
       }
-    } else {
+    }
+    return;
+  }
+  for (uint32_t il = blockIdx.x * rows_per_block + lane_row; il < count; il += gridDim.x * rows_per_block) {
+    const uint32_t i = first + il;
+    const long anc = gdiag ? (a ? (long)a[il] : (long)i) : 0;
+    {
       // Student-t: a lane takes PPL = 4 pairs of its row at a time (the launcher gives a row a quarter of the
       // lanes; 1 below d = 7), so that their eight chi^2 draws go through chi_square_batch together -- with two
       // draws per batch the wave pays the slow path of nearly every batch (smallops.h): 1400 -> 1165 us for
@@ -175,7 +223,7 @@ hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const
   while ((1 << pw_log2) < pairs && pw_log2 < 8) ++pw_log2;
   const bool four = kind == CUSMC_MVT && pairs >= 4;
   if (four) pw_log2 -= 2;  // four pairs per lane: eight chi^2 draws per batch
-  const long rows_per_block = 256 >> pw_log2;
+  const long rows_per_block = (long)(256 >> pw_log2) * (kind != CUSMC_MVT ? kDiagRows : 1);  // (Normal: four rows per lane and trip)
   long blocks = ((long)count + rows_per_block - 1) / rows_per_block;
   const long cap = (long)num_cus * 8;
   if (blocks > cap) blocks = cap;

@@ -92,6 +92,10 @@ static __device__ __forceinline__ void sincos_2pi(double u, double &c, double &s
 // (oracle/cusmc_oracle.c evaluates the same expressions with libm; the two agree to a few ulp).
 static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, double &z1)
 {
+#ifdef CUSMC_ABL_NO_BOXMULLER
+  z0 = (double)r.x, z1 = (double)r.z;
+  return;
+#endif
   const double u1 = 1.0 - u01_53(r.x, r.y);  // (0,1]
   const double u2 = u01_53(r.z, r.w);        // [0,1)
   const double rad = sqrt(-2.0 * ln_pos(u1));

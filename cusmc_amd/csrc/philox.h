@@ -24,6 +24,9 @@ struct u32x4 { uint32_t x, y, z, w; };
 __host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
                                                         uint32_t c3, uint32_t k0, uint32_t k1)
 {
+#ifdef CUSMC_ABL_NO_PHILOX
+  return u32x4{c0 * 2654435761u + k0, c1 ^ c0, c2 + k1, c3 ^ c1 * 40503u};
+#endif
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
