@@ -92,7 +92,7 @@ static __device__ __forceinline__ void sincos_2pi(double u, double &c, double &s
 // (oracle/cusmc_oracle.c evaluates the same expressions with libm; the two agree to a few ulp).
 static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, double &z1)
 {
-#ifdef CUSMC_ABL_NO_BOXMULLER
+#ifdef CUSMC_ABL_NO_BOXMULLER  // ablation builds only (scripts/calib/prop_time.py): what ln, sqrt and sincos cost a kernel
   z0 = (double)r.x, z1 = (double)r.z;
   return;
 #endif

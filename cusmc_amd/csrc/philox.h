@@ -24,7 +24,7 @@ struct u32x4 { uint32_t x, y, z, w; };
 __host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
                                                         uint32_t c3, uint32_t k0, uint32_t k1)
 {
-#ifdef CUSMC_ABL_NO_PHILOX
+#ifdef CUSMC_ABL_NO_PHILOX  // ablation builds only (scripts/calib/prop_time.py): what the ten rounds cost a kernel
   return u32x4{c0 * 2654435761u + k0, c1 ^ c0, c2 + k1, c3 ^ c1 * 40503u};
 #endif
 #pragma unroll
