@@ -545,6 +545,36 @@ def test_propagate_diagonal_models(cs, oracle, d, dist, nu):
     assert np.allclose(init.cpu().numpy(), want0, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("d", [2, 64])
+def test_propagate_diagonal_models_on_8_byte_aligned_rows(cs, oracle, d):
+    """The diagonal kernel moves 16-byte pieces when d is even and both batches are 16-byte aligned;
+    a batch that starts 8 bytes into an allocation takes the element-wise path: same values."""
+    import torch
+    rng = np.random.default_rng(d + 171)
+    N = 1500 + 1
+    Xp = rng.standard_normal((N, d))
+    a = rng.integers(0, N, N).astype(np.uint32)
+    G = np.diag(0.5 + rng.random(d))
+    Q = np.diag(0.1 + rng.random(d))
+    want = oracle.propagate(Xp, a, G, Q, "mvn", 0.0, 1.0, seed=79, step=3)
+    ctx = cs.api.default_context().use_torch_stream()
+    ad = torch.from_numpy(a.astype(np.int32)).cuda()
+    flat_in = torch.empty(N * d + 1, dtype=torch.float64, device="cuda")
+    flat_out = torch.full((N * d + 2,), float("nan"), dtype=torch.float64, device="cuda")
+    Xd = flat_in[1:].view(N, d)
+    Xd.copy_(torch.from_numpy(Xp))
+    out = flat_out[1:N * d + 1].view(N, d)
+    assert Xd.data_ptr() % 16 == 8 and out.data_ptr() % 16 == 8
+    cs.api.propagate_dev(Xd, ad, G, Q, out, "mvn", 0.0, 1.0, seed=79, step=3, ctx=ctx)
+    torch.cuda.synchronize()
+    assert np.allclose(out.cpu().numpy(), want, rtol=1e-9, atol=1e-9)
+    assert bool(torch.isnan(flat_out[0])) and bool(torch.isnan(flat_out[-1]))
+    aligned = torch.empty(N, d, dtype=torch.float64, device="cuda")
+    cs.api.propagate_dev(Xd.clone(), ad, G, Q, aligned, "mvn", 0.0, 1.0, seed=79, step=3, ctx=ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(aligned, out)
+
+
 @pytest.mark.parametrize("d", [16, 24, 64, 100, 128, 131, 160, 256])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0)])
 def test_propagate_diagonal_G_dense_Q(cs, oracle, d, dist, nu):
