@@ -249,7 +249,11 @@ static __device__ __forceinline__ uint32_t metropolis_chain(const double *__rest
       const u32x4 r = philox4x32_10(i, n + c, step, 1u, k0, k1);
       u[c] = u01_53(r.x, r.y);
       j[c] = uint_below(r.z, r.w, N);
+#ifdef CUSMC_ABL_MH_COALESCED  // ablation builds only (scripts/calib/mh_time.py): the chain without its random gather
+      wj[c] = w[(i + n + c) % N] + (double)(j[c] & 1);
+#else
       wj[c] = w[j[c]];
+#endif
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
