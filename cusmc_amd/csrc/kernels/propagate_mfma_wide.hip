@@ -61,6 +61,20 @@ size_t propagate_wide_lds_bytes(int nb, bool mvt)
 // MODE 0: x = [diag(c)] Q xi + m0     (tail = m0, d doubles)
 //      1: x = [diag(c)] Q xi + G x_prev[a]   (tail = fragments of G)
 //      4: x = [diag(c)] Q xi + g .* x_prev[a]   (tail = diag(G), d doubles)
+// Calibration hook (scripts/calib/pw_phases.hip; off in the library): wave 0 of every workgroup adds the s_memtime
+// ticks between the phase boundaries of a group to g_pw_phases[8 blockIdx + phase].
+#ifdef CUSMC_PW_PHASES
+__device__ unsigned long long g_pw_phases[8 * 1024];
+#define PW_STAMP(k)                                                                      \
+  do {                                                                                   \
+    const unsigned long long now_ = __builtin_readcyclecounter();                        \
+    if (threadIdx.x == 0 && (k) > 0) g_pw_phases[8 * blockIdx.x + (k)] += now_ - pw_t_;  \
+    pw_t_ = now_;                                                                        \
+  } while (0)
+#else
+#define PW_STAMP(k) do { } while (0)
+#endif
+
 template <int NB, bool MVT, int MODE, bool PAD>
 __global__ __launch_bounds__(512) void propagate_wide_kernel(
     float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
@@ -84,7 +98,23 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
   // this wave's share of a fill: slabs w + 8 kb, kb = 0 .. NB - 1 -- tile ft, half fh2 of every k-block
   const int ft = w & 3, fh2 = w >> 2;
 
+#ifdef CUSMC_PW_PHASES
+  unsigned long long pw_t_ = 0;
+#endif
+  // the ancestor index of the lane's fill particle, fetched one group AHEAD (Normal, dense G): the gather's addresses
+  // depend on it, vmcnt retires in order, and a load issued at the top of a group would wait for the 32 stores of the
+  // previous group's epilogue to drain first
+  auto ancestor_of = [&](long gg) -> uint32_t {
+    const long fl = gg * kWideGroup + 16 * ft + p;
+    const long cl = fl < (long)count ? fl : (long)count - 1;
+    return a ? a[cl] : first + (uint32_t)cl;
+  };
+  uint32_t anc_ahead = 0;
+  if constexpr (HAS_G && !MVT) {
+    if ((long)blockIdx.x < num_groups) anc_ahead = ancestor_of(blockIdx.x);
+  }
   for (long g = blockIdx.x; g < num_groups; g += gridDim.x) {
+    PW_STAMP(0);
     const long base = g * kWideGroup;  // first local row of the group
     const long flocal = base + 16 * ft + p;
     const bool flive = flocal < (long)count;
@@ -94,7 +124,7 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
     // constants on top of those registers would spill in the multiply; the exposed round trip is ~1.5 %) ----------
     v2d xg[HAS_G ? NB : 1];
     auto gather = [&]() {
-      const uint32_t anc = a ? a[flive ? flocal : (long)count - 1] : fgi;
+      const uint32_t anc = MVT ? (a ? a[flive ? flocal : (long)count - 1] : fgi) : anc_ahead;
       const double *row = X_prev + (long)anc * d;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
@@ -119,7 +149,9 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
       }
       reinterpret_cast<v2d *>(sB + (w + 8 * kb) * 128)[lane] = v2d{z0, z1};
     }
+    PW_STAMP(1);
     __syncthreads();
+    PW_STAMP(2);
     // ---- multiply: blocks cb0 (and cb1) x the four tiles ----------------------------------------------------
     v4d acc[2][T];
 #pragma unroll
@@ -200,6 +232,7 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
       }
     };
     multiply(fragsQ);
+    PW_STAMP(3);
     // lane (p, h), register r of block b holds output dim j = 16 cb_b + h + 4 r of particle p
     auto jof = [&](int c) { return 16 * ((c >> 2) ? cb1 : cb0) + h + 4 * (c & 3); };
     auto ok = [&](int c) { return ((c >> 2) == 0 || two) && (!PAD || jof(c) < d); };
@@ -245,8 +278,13 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
       __syncthreads();  // every wave has read the normals: the slabs take the gathered rows
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) reinterpret_cast<v2d *>(sB + (w + 8 * kb) * 128)[lane] = xg[kb];
+      PW_STAMP(4);
       __syncthreads();
       multiply(tail);
+    }
+    PW_STAMP(5);
+    if constexpr (HAS_G && !MVT) {
+      if (g + gridDim.x < num_groups) anc_ahead = ancestor_of(g + gridDim.x);  // (ahead of the stores below)
     }
     // ---- epilogue ------------------------------------------------------------------------------------
 #pragma unroll
@@ -270,7 +308,9 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
         }
       }
     }
+    PW_STAMP(6);
     __syncthreads();  // every wave has read the slabs: the next group may overwrite them
+    PW_STAMP(7);
   }
 }
 
