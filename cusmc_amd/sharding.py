@@ -88,19 +88,24 @@ def _all_to_all(out, inp, out_splits, in_splits, group=None):
     return out
 
 
-def exchange_rows(x_local, a_local, n_total, group=None, stats=None):
+def exchange_row_table(x_local, a_local, n_total, group=None, stats=None):
     """x_full[a_local[i]] for this rank's ancestors WITHOUT gathering x_full: every rank asks the owner
     of each ancestor for that row (one all-to-all of indices, 4 bytes each) and gets the rows back (one
     all-to-all of rows).  Per rank and step that is count * (R-1)/R rows in -- N/R of them -- where the
     all-gather of x_{t-1} brought in all N: 56 MB instead of 448 MB at N = 1e6, d = 64, R = 8
     (1.75 instead of 14 MB at d = 2).  x_local: this rank's rows [first, first+count) of x_{t-1};
-    a_local: int32/int64 GLOBAL ancestor indices of this rank's particles.  Returns count x d rows in
-    the order of a_local.  `stats`, if given, accumulates the bytes this rank sent and received."""
+    a_local: int32/int64 GLOBAL ancestor indices of this rank's particles.
+
+    Returns (table, idx), idx int32: the ancestor row of particle i is table[idx[i]].  The rows are NOT
+    put in particle order here: the proposal kernels gather through an index table anyway
+    (cusmc_propagate_dev's a_dev), so handing them the received rows and the inverse permutation saves a
+    pass over the rows; exchange_rows() materialises table[idx] for callers that want the rows.
+    `stats`, if given, accumulates the bytes this rank sent and received."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world == 1:
+        return x_local, a_local.to(torch.int32)
     counts = shard_counts(n_total, world)
     first = sum(counts[:rank])
-    if world == 1:
-        return x_local[a_local.long()]
     dev = x_local.device
     bounds = torch.tensor([sum(counts[:k + 1]) for k in range(world - 1)], dtype=torch.int64, device=dev)
     a64 = a_local.to(torch.int64)
@@ -116,15 +121,21 @@ def exchange_rows(x_local, a_local, n_total, group=None, stats=None):
     rows_out = x_local[(asked.to(torch.int64) - first)]      # the rows my peers asked for, in their order
     rows_in = torch.empty((sum(send_l),) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=dev)
     _all_to_all(rows_in, rows_out, send_l, recv_l, group)
-    out = torch.empty_like(rows_in)
-    out[order] = rows_in
+    inv = torch.empty(order.shape[0], dtype=torch.int32, device=dev)
+    inv[order] = torch.arange(order.shape[0], dtype=torch.int32, device=dev)  # particle order[k] asked for row k
     if stats is not None:
         row_b = x_local[0].numel() * x_local.element_size() if x_local.shape[0] else 0
         off = sum(send_l) - send_l[rank]
         stats["index_bytes_out"] = stats.get("index_bytes_out", 0) + 4 * off
         stats["row_bytes_in"] = stats.get("row_bytes_in", 0) + row_b * off
         stats["row_bytes_out"] = stats.get("row_bytes_out", 0) + row_b * (sum(recv_l) - recv_l[rank])
-    return out
+    return rows_in, inv
+
+
+def exchange_rows(x_local, a_local, n_total, group=None, stats=None):
+    """exchange_row_table() with the rows put in the order of a_local: count x d."""
+    table, idx = exchange_row_table(x_local, a_local, n_total, group, stats)
+    return table[idx.long()]
 
 
 def run_filter_sharded(N, T, init_fn, step_fn=None, group=None, resample_fn=None, move_fn=None, stats=None):
@@ -165,7 +176,10 @@ def run_filter_sharded(N, T, init_fn, step_fn=None, group=None, resample_fn=None
             a, x, w = step_fn(t, w_full, X_full, first, count)
         else:
             a = resample_fn(t, w_full, first, count)
-            x_anc = exchange_rows(x, a, N, group, stats) if world > 1 else x[a.long()]
+            if getattr(move_fn, "takes_row_table", False):  # (table, idx): the proposal kernel does the gather
+                x_anc = exchange_row_table(x, a, N, group, stats) if world > 1 else (x, a.to(torch.int32))
+            else:
+                x_anc = exchange_rows(x, a, N, group, stats) if world > 1 else x[a.long()]
             x, w = move_fn(t, x_anc, first, count)
         X_hist.append(x)
         w_hist.append(w)
@@ -221,21 +235,21 @@ def gpu_filter_callables_exchange(Y, m0, C0, F, G, V, W, df=0.0, distribution="m
     F, G, W = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (F, G, W))
     Qw = api.eigenSolver(W)
     scale = api.SQRT3 if compat else 1.0
-    ident = {}
-
     def resample_fn(t, w_full, first, count):
         a = torch.empty(count, dtype=torch.int32, device="cuda")
         api.Sampler.metropolis_hastings_dev(w_full, a, B=B, t=t, seed=seed, first=first, ctx=ctx)
         return a
 
     def move_fn(t, x_anc, first, count):
-        if count not in ident:
-            ident[count] = torch.arange(count, dtype=torch.int32, device="cuda")
+        # x_anc = (table, idx): particle i descends from table[idx[i]] -- the rows as they arrived from their
+        # owners; the proposal kernel gathers through idx (cusmc_propagate_dev's a_dev), no reordering pass
+        table, idx = x_anc
         x = torch.empty(count, d, dtype=torch.float64, device="cuda")
         w = torch.empty(count, dtype=torch.float64, device="cuda")
-        api.propagate_dev(x_anc.contiguous(), ident[count], G, Qw, x, kind=distribution, nu=df, scale=scale, seed=seed,
+        api.propagate_dev(table.contiguous(), idx.contiguous(), G, Qw, x, kind=distribution, nu=df, scale=scale, seed=seed,
                           step=t, first=first, ctx=ctx)
         obs.reweight_dev(x, Y[:, t], F, w, log=False)
         return x, w
+    move_fn.takes_row_table = True
 
     return init_fn, resample_fn, move_fn, obs
