@@ -7,7 +7,7 @@
 // Why a second kernel.  At d = 256 the block-triangular factor is 278 KB: it fits neither the
 // register file nor LDS, and one wave cannot hold 16 output blocks of accumulators for several
 // particle tiles.  So the OUTPUT dimension is split over the waves of a workgroup:
-//   * one workgroup per CU; it walks groups of GP particles (32, or 64 at d = 128);
+//   * one workgroup per CU; it walks groups of GP particles (32; 48 at NB = 12, see wide_gp());
 //   * a wave owns the PAIR of output blocks (q, NB-1-q) for the group's two particle tiles (NB = 12:
 //     four pairs and four single blocks -- see wide_waves()).  In the triangular form block cb needs
 //     k-blocks 0..cb, so every pair costs (q+1) + (NB-q) = NB+1 block-products: all waves carry
@@ -54,7 +54,10 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // 18 where 19.5 would be perfect (six pair-waves would leave 26, 26, 13, 13: the first NB = 12 mapping,
 // 48.8 TFLOP/s at d = 192).
 __host__ __device__ constexpr int wide_waves(int nb) { return (void)nb, 8; }
-__host__ __device__ constexpr int wide_gp(int nb) { return (void)nb, 32; }  // particles per group
+// particles per group: 32, and 48 at NB = 12, the one block count whose two staging buffers of three tiles fit
+// the 160 KB of LDS (147 KB): a group costs ~2000 cycles that are not MFMAs whatever its size, so a tile more per
+// barrier is worth 68 -> 7x % matrix-core utilisation at d = 177 .. 192
+__host__ __device__ constexpr int wide_gp(int nb) { return nb == 12 ? 48 : 32; }
 struct WideMap { int lo[8], hi[8]; };
 __host__ __device__ constexpr WideMap wide_map(int nb)
 {
@@ -111,7 +114,7 @@ static long wide_stream_frags(int nb, int w)
 static size_t wide_lds_bytes(int nb)
 {
   const int tiles = wide_gp(nb) / 16;
-  return (size_t)(2 * nb * 4 * tiles * 64 + 2 * wide_waves(nb) * 32 + 32 * nb) * sizeof(double);
+  return (size_t)(2 * nb * 4 * tiles * 64 + 2 * wide_waves(nb) * wide_gp(nb) + 32 * nb) * sizeof(double);
 }
 
 size_t mfma_wide_frag_doubles(int nb)
@@ -169,8 +172,8 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
   constexpr int XBUF = NB * 4 * TILES * 64;  // doubles per staging buffer
   extern __shared__ double lds[];
   double *sX = lds;                  // [2][NB][2 halves][TILES][64 lanes][2]
-  double *sPartial = sX + 2 * XBUF;  // [2][WAVES][32 particles]
-  double *sShift = sPartial + 2 * WAVES * 32;
+  double *sPartial = sX + 2 * XBUF;  // [2][WAVES][GP particles]
+  double *sShift = sPartial + 2 * WAVES * GP;
   double *sBias = sShift + 16 * NB;
 
   for (int i = threadIdx.x; i < 16 * NB; i += THREADS) {
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 
   __syncthreads();  // the first group is staged
   auto run = [&](auto tpw_tag) {
-  constexpr int TPW = decltype(tpw_tag)::value;  // tiles per wave: 2, or 1 for the split pairs of NB = 12
+  constexpr int TPW = decltype(tpw_tag)::value;  // tiles per wave = tiles per group: 2, or 3 at NB = 12
   int parity = 0;
   for (long g = blockIdx.x; g < num_groups; g += G, parity ^= 1) {
     // this wave's two tiles of the current buffer: slab (kb, h2, t) holds, per lane, the operands
@@ -391,20 +394,20 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
         for (int r = 0; r < 4; ++r) qq = fma(acc[t][m][r], acc[t][m][r], qq);
       qq += __shfl_xor(qq, 16);
       qq += __shfl_xor(qq, 32);
-      if (h == 0) sPartial[(parity * WAVES + w) * 32 + (tile0 + t) * 16 + p] = qq;
+      if (h == 0) sPartial[(parity * WAVES + w) * GP + (tile0 + t) * 16 + p] = qq;
     }
     __syncthreads();  // partials visible; the loader has completed the other buffer
-    if (w == 0 && lane < 32) {  // fixed summation order over the waves -> bitwise reproducible
-      const double *sp = sPartial + parity * WAVES * 32 + lane;
+    if (w == 0 && lane < GP) {  // fixed summation order over the waves -> bitwise reproducible
+      const double *sp = sPartial + parity * WAVES * GP + lane;
       double tot = sp[0];
 #pragma unroll
-      for (int k = 1; k < WAVES; ++k) tot += sp[k * 32];
+      for (int k = 1; k < WAVES; ++k) tot += sp[k * GP];
       const long row = g * GP + lane;
       if (row < N) out[row] = finish_wide(tot, ep);
     }
   }
   };
-  run(std::integral_constant<int, 2>{});
+  run(std::integral_constant<int, TILES>{});
 }
 
 template <int NB>
