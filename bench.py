@@ -205,7 +205,10 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # CUSMC_BENCH_FORCE_DIST=1 under a one-rank launcher: the RCCL group is created and every barrier / reduction
+    # below goes through it -- the closest a one-GPU box gets to the multi-GPU control path (tests/test_bench_cli.py)
+    dist_on = world > 1 or (os.environ.get("CUSMC_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -221,7 +224,7 @@ def main():
     mvn.ctx.use_torch_stream()  # launches go on torch's current stream, so torch events see them
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -245,7 +248,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
 
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
 
@@ -295,8 +298,8 @@ def main():
             "mh": None,
             "strong": None,
             "filter_step": None,
-            "ranks": world if world == 1 else int(dist.get_world_size()),
-            "backend": "single process" if world == 1 else dist.get_backend(),
+            "ranks": int(dist.get_world_size()) if dist_on else world,
+            "backend": dist.get_backend() if dist_on else "single process",
             "parity_max_rel_err_vs_oracle": None,
         }
         if traffic is not None:
@@ -346,7 +349,7 @@ def main():
             fn()
         barrier()
         tt = torch.tensor([(time.perf_counter() - t_) / reps], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if dist_on:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
@@ -381,7 +384,7 @@ def main():
             resample_once()
         barrier()
         tm = torch.tensor([(time.perf_counter() - t1) / reps], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if dist_on:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         mh_s = float(tm.item())
         mh = {"steps_per_s": n_total * MH_B / mh_s, "ms_per_resample": mh_s * 1e3,
@@ -462,12 +465,12 @@ def main():
         line.update({"cpu_baseline": cpu, "mh_steps_per_s": None if not mh else mh.get("steps_per_s"), "mh": mh,
                      "strong": strong, "filter_step": filt, "parity_max_rel_err_vs_oracle": parity})
         emit()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     if watchdog is not None:
         watchdog.cancel()
     mvn.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

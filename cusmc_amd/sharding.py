@@ -88,7 +88,7 @@ def _all_to_all(out, inp, out_splits, in_splits, group=None):
     return out
 
 
-def exchange_row_table(x_local, a_local, n_total, group=None, stats=None):
+def exchange_row_table(x_local, a_local, n_total, group=None, stats=None, _always_exchange=False):
     """x_full[a_local[i]] for this rank's ancestors WITHOUT gathering x_full: every rank asks the owner
     of each ancestor for that row (one all-to-all of indices, 4 bytes each) and gets the rows back (one
     all-to-all of rows).  Per rank and step that is count * (R-1)/R rows in -- N/R of them -- where the
@@ -102,7 +102,7 @@ def exchange_row_table(x_local, a_local, n_total, group=None, stats=None):
     pass over the rows; exchange_rows() materialises table[idx] for callers that want the rows.
     `stats`, if given, accumulates the bytes this rank sent and received."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not _always_exchange:  # (_always_exchange: lets a one-rank RCCL group run the collectives, tests only)
         return x_local, a_local.to(torch.int32)
     counts = shard_counts(n_total, world)
     first = sum(counts[:rank])
