@@ -156,6 +156,21 @@ static __device__ __forceinline__ double finish_wide(double q, const Epilogue &e
 
 struct WideStreams { int byte_off[8]; };  // start of each wave's fragment stream
 
+// Calibration hook (scripts/calib/lw_phases.hip; off in the library): every compute wave adds the s_memtime ticks it
+// spends per group (0) in the k loop, (1) in the reduction and its LDS write, (2) at the barrier, (3) after it, to
+// g_lw_phases[(blockIdx 8 + wave) 4 + phase].
+#ifdef CUSMC_LW_PHASES
+__device__ unsigned long long g_lw_phases[1024 * 8 * 4];
+#define LW_STAMP(k)                                                                                 \
+  do {                                                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();                                   \
+    if (lane == 0) g_lw_phases[((size_t)blockIdx.x * 8 + w) * 4 + (k)] += now_ - lw_t_;            \
+    lw_t_ = now_;                                                                                   \
+  } while (0)
+#else
+#define LW_STAMP(k) do { } while (0)
+#endif
+
 // ABL (scripts/calib only; 0 in the library): 1 = fragments not re-fetched, 2 = next group's rows
 // not fetched, 3 = neither.  Attribution of stall time; results are wrong by construction.
 template <int NB, bool CENTRED, bool SHIFT, int ABL = 0, bool PAD = false>
@@ -284,7 +299,11 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
   auto run = [&](auto tpw_tag) {
   constexpr int TPW = decltype(tpw_tag)::value;  // tiles per wave = tiles per group: 2, or 3 at NB = 12
   int parity = 0;
+#ifdef CUSMC_LW_PHASES
+  unsigned long long lw_t_ = __builtin_readcyclecounter();
+#endif
   for (long g = blockIdx.x; g < num_groups; g += G, parity ^= 1) {
+    LW_STAMP(3);
     // this wave's two tiles of the current buffer: slab (kb, h2, t) holds, per lane, the operands
     // of k-steps 2 h2 and 2 h2 + 1
     const v2d *xw = reinterpret_cast<const v2d *>(sX + parity * XBUF) + tile0 * 64 + lane;
@@ -374,6 +393,9 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
       }
       return odd;
     };
+    // (Tried, r02: a wave priority that falls with its progress, so that the two waves of a SIMD finish together
+    // instead of the older one in 70 % of a group and the younger one in 92 % -- 1.5 .. 5 % SLOWER; and the extreme
+    // pairs on the younger waves -- 1 .. 2 % slower: profiles/r02_experiments.txt.)
     // (Tried: in the single-member phase the 16 fragment registers can hold a ring of four k-blocks,
     // i.e. fragments requested three k-blocks ahead at no register cost.  No gain -- 661..670 us
     // against 654..660 in the calibration run -- so the fragment latency is not what the two streams
@@ -383,6 +405,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
       run_phase(std::integral_constant<int, 1>{}, lo + 1, hi + 1, odd);
     }
 
+    LW_STAMP(0);
     // partial sums of squares over this wave's output blocks, per particle: slot [wave][tile][p]
     // (an absent member's accumulator is zero)
 #pragma unroll
@@ -396,7 +419,9 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
       qq += __shfl_xor(qq, 32);
       if (h == 0) sPartial[(parity * WAVES + w) * GP + (tile0 + t) * 16 + p] = qq;
     }
+    LW_STAMP(1);
     __syncthreads();  // partials visible; the loader has completed the other buffer
+    LW_STAMP(2);
     if (w == 0 && lane < GP) {  // fixed summation order over the waves -> bitwise reproducible
       const double *sp = sPartial + parity * WAVES * GP + lane;
       double tot = sp[0];
