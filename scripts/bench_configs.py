@@ -151,9 +151,14 @@ def main():
         t = time.perf_counter() - t0  # (the result stays alive: releasing 2.4 GB of pages costs 0.1 s by itself)
         del res
         rows.append((name, "%.3g particle-steps/s" % (N * (T - 1) / t), "%.3f s wall" % t, "-", "-"))
-    print("| config | rate | time | algorithmic HBM | MFMA |\n|---|---|---|---|---|")
+    # last column: the larger of the two roofline fractions -- algorithmic bytes against the 8 TB/s HBM spec, matrix-core
+    # flops against the 78.6 TFLOP/s f64 MFMA peak (the kernels below ~0.3 on both are VALU- or latency-bound: DESIGN.md 4)
+    print("| config | rate | time | algorithmic HBM | MFMA | of the nearer roofline |\n|---|---|---|---|---|---|")
     for r in rows:
-        print("| " + " | ".join(r) + " |")
+        hbm = float(r[3].split()[0]) / 8.0 if r[3] != "-" else 0.0
+        mfma = float(r[4].split()[0]) / 78.6 if r[4] != "-" else 0.0
+        frac = "-" if max(hbm, mfma) == 0.0 else "%.0f %% (%s)" % (100 * max(hbm, mfma), "HBM" if hbm >= mfma else "MFMA")
+        print("| " + " | ".join(r) + " | " + frac + " |")
 
 
 if __name__ == "__main__":
