@@ -21,6 +21,7 @@ _vp, _i, _i64, _u32, _u64, _f, _d = (C.c_void_p, C.c_int, C.c_int64, C.c_uint32,
 _pp = C.POINTER(C.c_void_p)
 SYMBOLS = [
     ("cusmc_version", C.c_char_p, []),
+    ("cusmc_rng_contract", _i, []),
     ("cusmc_last_error", C.c_char_p, []),
     ("cusmc_device_count", _i, []),
     ("cusmc_stream_key", _u64, [_u64, _u64]),

@@ -359,7 +359,8 @@ int plan_affine(cusmc_dist *dist, const double *y, const double *F)
 
 // ---- library / context ----------------------------------------------------------------------
 
-CUSMC_EXPORT const char *cusmc_version(void) { return "cusmc-hip 0.2 (gfx950)"; }
+CUSMC_EXPORT const char *cusmc_version(void) { return "cusmc-hip 0.3 (gfx950; rng contract 2)"; }
+CUSMC_EXPORT int cusmc_rng_contract(void) { return 2; }
 
 // One independent Philox key per R-level call: the (call + 1)-th output of SplitMix64 seeded with
 // `seed`.  The R-level draw / resample / run() entry points have no seed argument (the reference

@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
       if (j + 1 < D) xi[j + 1] = scale * z1;
     }
     double chi[D];
-    if (MVT)  // the particle's D chi^2 draws together (smallops.h: chi_square_batch)
-      chi_square_batch<D>(chi_setup(nu), i, step, k0, k1, [](int c) { return c; }, [](int) { return true; }, chi);
+    if (MVT)  // the particle's D chi^2 draws together (smallops.h: chi_pair_batch)
+      chi_square_all<D>(chi_setup(nu), i, step, k0, k1, chi);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       double s = 0.0;

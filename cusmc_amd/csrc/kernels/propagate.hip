@@ -98,13 +98,17 @@ __global__ __launch_bounds__(T) void propagate_kernel(
 // spills: 540 .. 830 us)
 constexpr int kDiagRows = 4;
 
-template <bool MVT, int PPL = 4>  // PPL: pairs a lane takes at a time (Student-t)
+// CHI: 0 Normal; 1, 2 Student-t with the closed-form chi^2 of nu = 2, 4 (RNG contract 2: one more Philox block and two
+// ln per pair, no rejection -- same loop as the Normal draw); 3 Student-t by Marsaglia-Tsang (any other nu), PPL pairs
+// of a row per lane and trip
+template <int CHI, int PPL = 4>
 __global__ __launch_bounds__(256) void propagate_diag_kernel(
     float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
     const double *__restrict__ gdiag, const double *__restrict__ qdiag, const double *__restrict__ m0,
     int d, int pw_log2, double scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t domain,
     uint32_t first, uint32_t count, double *__restrict__ X_out)
 {
+  constexpr bool MVT = CHI != 0;
   // 2^pw_log2 lanes per row (>= the number of pairs up to 256, no division anywhere); a block
   // covers 256 >> pw_log2 rows per pass
   const int pairs = (d + 1) / 2;
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
   const int lane_pr = (int)threadIdx.x & (pw - 1);
   const uint32_t lane_row = threadIdx.x >> pw_log2;
   const ChiSquare cs = chi_setup(MVT ? nu : 2.0f);
-  if constexpr (!MVT) {
-    // Normal: a lane takes its pair of U = 4 rows at a time -- the four ancestor indices, then the four 16-byte
+  if constexpr (CHI != 3) {
+    // A lane takes its pair of U = 4 rows at a time -- the four ancestor indices, then the four 16-byte
     // pieces of the ancestors' rows are requested before the first normal is drawn.  One row at a time, a CU's 32
     // waves kept 32 KB in flight and the kernel ran at what that buys (3.8 TB/s of gather + store, RNG on top:
     // 375 us for 1e6 x 64; 302 us now, which is the VALU time of the draws: ~1400 cycles per wave and pair);
@@ -155,8 +159,15 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
           if (il[u] >= count) continue;
           double z0, z1;
           normal_pair(philox4x32_10(first + il[u], (uint32_t)pr, step, domain, k0, k1), z0, z1);
-          const double o0 = fma(q0, scale * z0, 0.0) + (gdiag ? fma(t0, x[u][0], 0.0) : t0);
-          const double o1 = fma(q1, scale * z1, 0.0) + (gdiag ? fma(t1, x[u][1], 0.0) : t1);
+          double s0 = fma(q0, scale * z0, 0.0), s1 = fma(q1, scale * z1, 0.0);
+          if constexpr (MVT) {
+            double c0, c1;
+            chi_closed_pair<CHI>(first + il[u], (uint32_t)pr, step, k0, k1, c0, c1);
+            s0 = fma(s0, sqrt((double)nu / c0), 0.0);  // (an fma, so that no kernel contracts it with the add below)
+            s1 = fma(s1, sqrt((double)nu / c1), 0.0);
+          }
+          const double o0 = s0 + (gdiag ? fma(t0, x[u][0], 0.0) : t0);
+          const double o1 = s1 + (gdiag ? fma(t1, x[u][1], 0.0) : t1);
           double *dst = X_out + (long)il[u] * d + j;
           if (wide) {
             *reinterpret_cast<v2d *>(dst) = v2d{o0, o1};
@@ -173,10 +184,10 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
     const uint32_t i = first + il;
     const long anc = gdiag ? (a ? (long)a[il] : (long)i) : 0;
     {
-      // Student-t: a lane takes PPL = 4 pairs of its row at a time (the launcher gives a row a quarter of the
-      // lanes; 1 below d = 7), so that their eight chi^2 draws go through chi_square_batch together -- with two
+      // Student-t by rejection: a lane takes PPL = 4 pairs of its row at a time (the launcher gives a row a quarter
+      // of the lanes; 1 below d = 7), so that their eight chi^2 draws go through chi_pair_batch together -- with two
       // draws per batch the wave pays the slow path of nearly every batch (smallops.h): 1400 -> 1165 us for
-      // 1e6 x 64; the pairs' values, same operations as above
+      // 1e6 x 64 under contract 1; the pairs' values, same operations as above
       for (int pr0 = lane_pr; pr0 < pairs; pr0 += PPL * pw) {
         double z[PPL][2];
 #pragma unroll
@@ -192,8 +203,7 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
           }
         }
         double chi[2 * PPL];
-        chi_square_batch<2 * PPL>(cs, i, step, k0, k1, [&](int c) { return 2 * (pr0 + (c >> 1) * pw) + (c & 1); },
-                            [&](int c) { return 2 * (pr0 + (c >> 1) * pw) + (c & 1) < d; }, chi);
+        chi_pair_batch<PPL>(cs, i, step, k0, k1, [&](int c) { return pr0 + c * pw; }, [&](int c) { return pr0 + c * pw < pairs; }, chi);
 #pragma unroll
         for (int q = 0; q < PPL; ++q)
 #pragma unroll
@@ -221,13 +231,15 @@ hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const
   const int pairs = (d + 1) / 2;
   int pw_log2 = 0;
   while ((1 << pw_log2) < pairs && pw_log2 < 8) ++pw_log2;
-  const bool four = kind == CUSMC_MVT && pairs >= 4;
+  const int chi = kind != CUSMC_MVT ? 0 : nu == 2.0f ? 1 : nu == 4.0f ? 2 : 3;  // (smallops.h: chi_setup)
+  const bool four = chi == 3 && pairs >= 4;
   if (four) pw_log2 -= 2;  // four pairs per lane: eight chi^2 draws per batch
-  const long rows_per_block = (long)(256 >> pw_log2) * (kind != CUSMC_MVT ? kDiagRows : 1);  // (Normal: four rows per lane and trip)
+  const long rows_per_block = (long)(256 >> pw_log2) * (chi != 3 ? kDiagRows : 1);  // (four rows per lane and trip)
   long blocks = ((long)count + rows_per_block - 1) / rows_per_block;
   const long cap = (long)num_cus * 8;
   if (blocks > cap) blocks = cap;
-  auto kern = kind != CUSMC_MVT ? propagate_diag_kernel<false> : four ? propagate_diag_kernel<true, 4> : propagate_diag_kernel<true, 1>;
+  auto kern = chi == 0 ? propagate_diag_kernel<0> : chi == 1 ? propagate_diag_kernel<1> : chi == 2 ? propagate_diag_kernel<2>
+              : four ? propagate_diag_kernel<3, 4> : propagate_diag_kernel<3, 1>;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, nu, X_prev, a, gdiag, qdiag, m0, d,
                      pw_log2, scale, (uint32_t)seed, (uint32_t)(seed >> 32), step, domain, first, count, X_out);
   return hipGetLastError();
@@ -321,8 +333,8 @@ __global__ __launch_bounds__(256) void propagate_small_kernel(
       if (j + 1 < D) xi[j + 1] = scale * z1;
     }
     double chi[D];
-    if (MVT)  // the particle's D chi^2 draws together (smallops.h: chi_square_batch)
-      chi_square_batch<D>(chi_setup(nu), i, step, k0, k1, [](int c) { return c; }, [](int) { return true; }, chi);
+    if (MVT)  // the particle's D chi^2 draws together (smallops.h: chi_pair_batch)
+      chi_square_all<D>(chi_setup(nu), i, step, k0, k1, chi);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       double s = 0.0;

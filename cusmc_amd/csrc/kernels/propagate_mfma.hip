@@ -184,9 +184,8 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
         if constexpr (MVT && HAS_Q) {
           if (cb % GB == 0) {
             const int cb0 = cb;
-            chi_square_batch<4 * GB>(cs, gi, step, k0, k1, [&](int c) { return 16 * (cb0 + (c >> 2)) + h + 4 * (c & 3); },
-                                     [&](int c) { return cb0 + (c >> 2) < NB && (!PAD || 16 * (cb0 + (c >> 2)) + h + 4 * (c & 3) < d); },
-                                     chi);
+            chi_square_clayout<GB>(cs, gi, step, k0, k1, h, [&](int b) { return 16 * (cb0 + b); },
+                                   [&](int b, int j) { return cb0 + b < NB && (!PAD || j < d); }, chi);
           }
         }
 #pragma unroll

@@ -234,8 +234,6 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
     multiply(fragsQ);
     PW_STAMP(3);
     // lane (p, h), register r of block b holds output dim j = 16 cb_b + h + 4 r of particle p
-    auto jof = [&](int c) { return 16 * ((c >> 2) ? cb1 : cb0) + h + 4 * (c & 3); };
-    auto ok = [&](int c) { return ((c >> 2) == 0 || two) && (!PAD || jof(c) < d); };
     if constexpr (MVT) {
       // Student-t: Q xi scaled per component by sqrt(nu / chi2) BEFORE G x_prev is added on top.  A batch of draws
       // wants ~150 registers; with the 64 accumulator registers live beside it hipcc spilled the accumulators to
@@ -257,7 +255,8 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
         const long local = base + 16 * t + p;
         const uint32_t gi = first + (uint32_t)(local < (long)count ? local : (long)count - 1);
         double chi[8];
-        chi_square_batch<8>(cs, gi, step, k0, k1, jof, ok, chi);
+        chi_square_clayout<2>(cs, gi, step, k0, k1, h, [&](int b) { return 16 * (b ? cb1 : cb0); },
+                              [&](int b, int j) { return (b == 0 || two) && (!PAD || j < d); }, chi);
 #pragma unroll
         for (int c = 0; c < 8; c += 2) {
           v2d *q = park + (((c >> 2) * T + t) * 2 + ((c >> 1) & 1)) * 64;

@@ -105,30 +105,36 @@ static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, do
   z1 = rad * s;
 }
 
-// chi^2_nu = 2 Gamma(nu/2, 1) by Marsaglia-Tsang, the reference's device sampler (curand_gamma,
-// src/mvt_dist.cu.cpp:20-61) including its squeeze test (:45); counter layout as
-// oracle/cusmc_oracle.c:chi_square_for -- attempt m < 63 of (particle, component j) takes its normal from
-// Philox block (particle, 64 j + m, step, 3) and its uniform from block (particle, 64 j + m, step, 5); the
-// a < 1 boost uniform is block (particle, 64 j + 63, step, 5).  Accept attempt m iff
-//     v = 1 + c z0 > 0   and   ( u < 1 - 0.0331 z0^4   or   ln u < z0^2/2 + dd - dd v^3 + dd ln v^3 ).
+// chi^2_nu draws, RNG CONTRACT 2 (restated in oracle/cusmc_oracle.c:chi_square_for).
+// Law: chi[j] ~ chi^2_nu per component, independent of each other and of the normals
+// (src/statistics.cc.cpp:366, 383-386; device helper src/mvt_dist.cu.cpp:20-61).  Keyed by the component PAIR
+// p = j / 2, half e = j % 2 -- the unit the proposal normals are keyed by:
+//   nu == 2 or 4   closed form chi^2_{2m} = -2 ln(u_1 .. u_m): ONE block (particle, p, step, 6) per pair, half e
+//                  takes words (2e, 2e+1) -- m = 1: one 52-bit uniform, m = 2: two 32-bit uniforms, all in (0, 1).
+//                  No rejection, no divergent branch.
+//   other nu       Marsaglia-Tsang, squeeze and a < 1 boost as the reference's helper.  Attempt m < 63 of pair p:
+//                  block (particle, 64 p + m, step, 3) -> Box-Muller -> (z0, z1) = the normals of halves (0, 1);
+//                  block (particle, 64 p + m, step, 5) -> words (2e, 2e+1) -> half e's uniform in (0, 1].  Accept iff
+//                      v = 1 + c z > 0   and   ( u < 1 - 0.0331 z^4   or   ln u < z^2/2 + dd - dd v^3 + dd ln v^3 ).
+//                  Boost uniform: block (particle, 64 p + 63, step, 5), words (2e, 2e+1).
+// Contract 1 spent two blocks and a Box-Muller pair per attempt AND COMPONENT (second normal and half of the
+// uniforms discarded): a Student-t component cost 3 - 4.6 x a Normal one (profiles/r02_summary.md).
 //
 // Cost model (f64 MFMA kernels: every VALU instruction is on the critical path; elsewhere: the proposal
-// kernels are RNG-bound).  One attempt is two Philox blocks and a Box-Muller pair; the log test adds two
-// ln.  The squeeze settles ~92 % of the attempts without a logarithm, ~96 % of the attempts accept -- but a
+// kernels are RNG-bound).  The squeeze settles ~92 % of the attempts without a logarithm, ~96 % accept -- but a
 // wave runs a branch as long as ONE of its 64 lanes needs it, so a per-draw loop executes its slow path on
-// nearly every draw (1 - 0.92^64) and its second attempt on most (1 - 0.96^64): ~2 x (attempt + 2 ln) per
-// draw, which is what round 1's version cost (29 x the Normal draw in the d = 2 filter).  chi_square_batch
-// therefore takes the K draws of a lane TOGETHER: first attempt and squeeze for all K with no branch, then
-// the few draws still open (8 % per lane: the wave makes max-over-lanes trips, ~4 of 16) go through the full
-// loop one per trip.  Same counters, same accept rule, same results as the draw-by-draw loop.
+// nearly every draw.  chi_pair_batch therefore takes the KP pairs of a lane TOGETHER: first attempt and squeeze
+// for all of them with no branch, then the few halves still open go through the full loop one per trip.
 struct ChiSquare {
   double dd, c, inv_a;
   bool boost;
+  int closed;  // 0: Marsaglia-Tsang; 1, 2: closed form with m = nu / 2 uniforms per component
 };
 static __device__ __forceinline__ ChiSquare chi_setup(float nu)
 {
   ChiSquare cs;
   double a = 0.5 * (double)nu;
+  cs.closed = nu == 2.0f ? 1 : nu == 4.0f ? 2 : 0;
   cs.boost = a < 1.0;
   cs.inv_a = 1.0 / a;
   if (cs.boost) a += 1.0;
@@ -136,92 +142,172 @@ static __device__ __forceinline__ ChiSquare chi_setup(float nu)
   cs.c = 1.0 / sqrt(9.0 * cs.dd);
   return cs;
 }
-// attempt (particle, jm = 64 j + m): its normal, v = 1 + c z0, and its uniform in (0, 1]
-static __device__ __forceinline__ void chi_attempt(const ChiSquare &cs, uint32_t particle, uint32_t jm, uint32_t step,
-                                                   uint32_t k0, uint32_t k1, double &z0, double &v, double &u)
+// closed form: both halves of pair p from one block
+template <int M>
+static __device__ __forceinline__ void chi_closed_pair(uint32_t particle, uint32_t p, uint32_t step, uint32_t k0,
+                                                       uint32_t k1, double &chi0, double &chi1)
 {
-  double z1;
-  normal_pair(philox4x32_10(particle, jm, step, 3u, k0, k1), z0, z1);
-  v = 1.0 + cs.c * z0;
-  const u32x4 r = philox4x32_10(particle, jm, step, 5u, k0, k1);
-  u = 1.0 - u01_53(r.x, r.y);
+  const u32x4 r = philox4x32_10(particle, p, step, 6u, k0, k1);
+  double P0, P1;
+  if (M == 1) {
+    P0 = ((double)(((((uint64_t)r.x << 32) | r.y)) >> 12) + 0.5) * 0x1.0p-52;
+    P1 = ((double)(((((uint64_t)r.z << 32) | r.w)) >> 12) + 0.5) * 0x1.0p-52;
+  } else {
+    P0 = fma((double)r.x, 0x1.0p-32, 0x1.0p-33) * fma((double)r.y, 0x1.0p-32, 0x1.0p-33);
+    P1 = fma((double)r.z, 0x1.0p-32, 0x1.0p-33) * fma((double)r.w, 0x1.0p-32, 0x1.0p-33);
+  }
+  chi0 = -2.0 * ln_pos(P0);
+  chi1 = -2.0 * ln_pos(P1);
 }
-// u < 1 - 0.0331 z0^4, as ONE fixed sequence of roundings (the oracle evaluates the same fma)
+// attempt m of pair p: the two normals, v = 1 + c z and the two uniforms in (0, 1]
+static __device__ __forceinline__ void chi_attempt_pair(const ChiSquare &cs, uint32_t particle, uint32_t pm, uint32_t step,
+                                                        uint32_t k0, uint32_t k1, double (&z)[2], double (&v)[2],
+                                                        double (&u)[2])
+{
+  normal_pair(philox4x32_10(particle, pm, step, 3u, k0, k1), z[0], z[1]);
+  v[0] = 1.0 + cs.c * z[0];
+  v[1] = 1.0 + cs.c * z[1];
+  const u32x4 r = philox4x32_10(particle, pm, step, 5u, k0, k1);
+  u[0] = 1.0 - u01_53(r.x, r.y);
+  u[1] = 1.0 - u01_53(r.z, r.w);
+}
+// u < 1 - 0.0331 z^4, as ONE fixed sequence of roundings (the oracle evaluates the same fma)
 static __device__ __forceinline__ bool chi_squeeze(double z0, double u)
 {
   const double z2 = z0 * z0;
   return u < fma(-(0.0331 * z2), z2, 1.0);
 }
-// the draw-by-draw loop: every attempt from m = 0 with the full rule; returns Gamma(a, 1) / boost
-static __device__ __forceinline__ double chi_loop(const ChiSquare &cs, uint32_t particle, uint32_t j, uint32_t step,
-                                                  uint32_t k0, uint32_t k1)
+// one half's walk through its attempts from m = 0 with the full rule; returns Gamma(a, 1) / boost
+static __device__ __forceinline__ double chi_loop(const ChiSquare &cs, uint32_t particle, uint32_t p, uint32_t e,
+                                                  uint32_t step, uint32_t k0, uint32_t k1)
 {
   double g = cs.dd;  // value if all 63 attempts reject (probability < 1e-60)
   for (uint32_t m = 0; m < 63u; ++m) {
-    double z0, v, u;
-    chi_attempt(cs, particle, j * 64u + m, step, k0, k1, z0, v, u);
-    if (v <= 0.0) continue;
-    v = v * v * v;
-    if (chi_squeeze(z0, u) || ln_pos(u) < 0.5 * z0 * z0 + cs.dd - cs.dd * v + cs.dd * ln_pos(v)) {
-      g = cs.dd * v;
+    double z[2], v[2], u[2];
+    chi_attempt_pair(cs, particle, p * 64u + m, step, k0, k1, z, v, u);
+    const double ze = e ? z[1] : z[0], ue = e ? u[1] : u[0];
+    double ve = e ? v[1] : v[0];
+    if (ve <= 0.0) continue;
+    ve = ve * ve * ve;
+    if (chi_squeeze(ze, ue) || ln_pos(ue) < 0.5 * ze * ze + cs.dd - cs.dd * ve + cs.dd * ln_pos(ve)) {
+      g = cs.dd * ve;
       break;
     }
   }
   return g;
 }
-static __device__ __forceinline__ double chi_boost(const ChiSquare &cs, uint32_t particle, uint32_t j, uint32_t step,
-                                                   uint32_t k0, uint32_t k1)
+static __device__ __forceinline__ void chi_boost_pair(const ChiSquare &cs, uint32_t particle, uint32_t p, uint32_t step,
+                                                      uint32_t k0, uint32_t k1, double &b0, double &b1)
 {
-  const u32x4 r = philox4x32_10(particle, j * 64u + 63u, step, 5u, k0, k1);
-  return pow(1.0 - u01_53(r.x, r.y), cs.inv_a);
+  const u32x4 r = philox4x32_10(particle, p * 64u + 63u, step, 5u, k0, k1);
+  b0 = pow(1.0 - u01_53(r.x, r.y), cs.inv_a);
+  b1 = pow(1.0 - u01_53(r.z, r.w), cs.inv_a);
 }
-// chi[c] = chi^2_nu draw of component jof(c) for the c < K with live(c); jof / live are evaluated for
-// run-time c as well (closed forms, not tables: no dynamically indexed registers).
-template <int K, typename JOf, typename Live>
-static __device__ __forceinline__ void chi_square_batch(const ChiSquare &cs, uint32_t particle, uint32_t step, uint32_t k0,
-                                                        uint32_t k1, JOf jof, Live live, double (&chi)[K])
+// chi[2 c + e] = chi^2_nu draw of component 2 pof(c) + e for the c < KP with live(c); pof / live are evaluated
+// for run-time c as well (closed forms, not tables: no dynamically indexed registers).  A dead pair gets 1.
+template <int KP, typename POf, typename Live>
+static __device__ __forceinline__ void chi_pair_batch(const ChiSquare &cs, uint32_t particle, uint32_t step, uint32_t k0,
+                                                      uint32_t k1, POf pof, Live live, double (&chi)[2 * KP])
 {
-  static_assert(K <= 32, "one pending bit per draw");
-  uint32_t pend = 0;
+  static_assert(KP <= 16, "one pending bit per draw");
 #pragma unroll
-  for (int c = 0; c < K; ++c) chi[c] = 1.0;
-  // A real loop, not K unrolled copies: unrolled, the K independent attempts are interleaved by the
+  for (int c = 0; c < 2 * KP; ++c) chi[c] = 1.0;
+  if (cs.closed) {  // (wave-uniform: nu is a launch parameter)
+    // a real loop for the same reason as below: KP unrolled copies of Philox + two ln keep ~40 registers each
+#pragma unroll 1
+    for (int c = 0; c < KP; ++c) {
+      if (!live(c)) continue;
+      double g0, g1;
+      if (cs.closed == 1) chi_closed_pair<1>(particle, (uint32_t)pof(c), step, k0, k1, g0, g1);
+      else chi_closed_pair<2>(particle, (uint32_t)pof(c), step, k0, k1, g0, g1);
+#pragma unroll
+      for (int cc = 0; cc < KP; ++cc) {
+        chi[2 * cc] = cc == c ? g0 : chi[2 * cc];
+        chi[2 * cc + 1] = cc == c ? g1 : chi[2 * cc + 1];
+      }
+    }
+    return;
+  }
+  uint32_t pend = 0;
+  // A real loop, not KP unrolled copies: unrolled, the independent attempts are interleaved by the
   // scheduler and their ~50 live registers each add up (100-200 VGPRs spilled in the matrix-core proposal);
   // the price is the select chain that files the result under a run-time c.
 #pragma unroll 1
-  for (int c = 0; c < K; ++c) {
+  for (int c = 0; c < KP; ++c) {
     if (!live(c)) continue;
-    double z0, v, u;
-    chi_attempt(cs, particle, (uint32_t)jof(c) * 64u, step, k0, k1, z0, v, u);
-    const bool ok = (v > 0.0) & chi_squeeze(z0, u);
-    const double g = cs.dd * (v * v * v);
-    pend |= ok ? 0u : 1u << c;
+    double z[2], v[2], u[2];
+    chi_attempt_pair(cs, particle, (uint32_t)pof(c) * 64u, step, k0, k1, z, v, u);
+    const bool ok0 = (v[0] > 0.0) & chi_squeeze(z[0], u[0]), ok1 = (v[1] > 0.0) & chi_squeeze(z[1], u[1]);
+    const double g0 = cs.dd * (v[0] * v[0] * v[0]), g1 = cs.dd * (v[1] * v[1] * v[1]);
+    pend |= (ok0 ? 0u : 1u << (2 * c)) | (ok1 ? 0u : 2u << (2 * c));
 #pragma unroll
-    for (int cc = 0; cc < K; ++cc) chi[cc] = cc == c ? g : chi[cc];
+    for (int cc = 0; cc < KP; ++cc) {
+      chi[2 * cc] = cc == c ? g0 : chi[2 * cc];
+      chi[2 * cc + 1] = cc == c ? g1 : chi[2 * cc + 1];
+    }
   }
   while (pend) {  // one open draw per lane per trip
     const int c = __builtin_ctz(pend);
     pend &= pend - 1u;
-    const double g = chi_loop(cs, particle, (uint32_t)jof(c), step, k0, k1);
+    const double g = chi_loop(cs, particle, (uint32_t)pof(c >> 1), (uint32_t)(c & 1), step, k0, k1);
 #pragma unroll
-    for (int cc = 0; cc < K; ++cc) chi[cc] = cc == c ? g : chi[cc];
+    for (int cc = 0; cc < 2 * KP; ++cc) chi[cc] = cc == c ? g : chi[cc];
   }
 #pragma unroll
-  for (int c = 0; c < K; ++c) {
-    chi[c] *= 2.0;
-    if (cs.boost) {  // (wave-uniform: nu is a launch parameter)
-      if (live(c)) chi[c] *= chi_boost(cs, particle, (uint32_t)jof(c), step, k0, k1);
+  for (int c = 0; c < KP; ++c) {
+    chi[2 * c] *= 2.0;
+    chi[2 * c + 1] *= 2.0;
+    if (cs.boost) {  // (wave-uniform)
+      if (live(c)) {
+        double b0, b1;
+        chi_boost_pair(cs, particle, (uint32_t)pof(c), step, k0, k1, b0, b1);
+        chi[2 * c] *= b0;
+        chi[2 * c + 1] *= b1;
+      }
     }
   }
+}
+// the D draws of one particle held by one lane (lane = particle kernels): chi[j], j < D
+template <int D>
+static __device__ __forceinline__ void chi_square_all(const ChiSquare &cs, uint32_t particle, uint32_t step, uint32_t k0,
+                                                      uint32_t k1, double (&chi)[D])
+{
+  constexpr int KP = (D + 1) / 2;
+  double tmp[2 * KP];
+  chi_pair_batch<KP>(cs, particle, step, k0, k1, [](int c) { return c; }, [](int) { return true; }, tmp);
+#pragma unroll
+  for (int j = 0; j < D; ++j) chi[j] = tmp[j];
 }
 // a single draw (callers that own one component per lane)
 static __device__ __forceinline__ double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, uint32_t k0,
                                                         uint32_t k1, float nu)
 {
   const ChiSquare cs = chi_setup(nu);
-  double chi[1];
-  chi_square_batch<1>(cs, particle, step, k0, k1, [&](int) { return j; }, [](int) { return true; }, chi);
-  return chi[0];
+  double chi[2];
+  chi_pair_batch<1>(cs, particle, step, k0, k1, [&](int) { return j >> 1; }, [](int) { return true; }, chi);
+  return (j & 1u) ? chi[1] : chi[0];
+}
+// The lane's draws in the matrix cores' C layout: lane (p, h) owns components blk(b) + h + 4 r, r < 4, of NBLK
+// 16-blocks, out[4 b + r].  Pairs (j, j + 1), j even, straddle the lanes h and h ^ 1 (16 lanes apart, the same
+// particle): the even-h lane draws the pairs of r = 0, 1, the odd-h lane those of r = 2, 3, each keeps the half
+// of its own parity and hands the other one over -- 2 pair draws per lane and block instead of 4 single ones.
+template <int NBLK, typename BlkOf, typename LiveJ>
+static __device__ __forceinline__ void chi_square_clayout(const ChiSquare &cs, uint32_t particle, uint32_t step,
+                                                          uint32_t k0, uint32_t k1, int h, BlkOf blk, LiveJ livej,
+                                                          double (&out)[4 * NBLK])
+{
+  const int e = h & 1, hb = h - e;
+  auto jof = [&](int c) { return blk(c >> 1) + hb + 4 * (2 * e + (c & 1)); };  // the even component of pair c
+  double mine[4 * NBLK];
+  chi_pair_batch<2 * NBLK>(cs, particle, step, k0, k1, [&](int c) { return jof(c) >> 1; }, [&](int c) { return livej(c >> 1, jof(c)); }, mine);
+#pragma unroll
+  for (int c = 0; c < 2 * NBLK; ++c) {
+    const double keep = e ? mine[2 * c + 1] : mine[2 * c], give = e ? mine[2 * c] : mine[2 * c + 1];
+    const double got = __shfl_xor(give, 16);
+    const int b = c >> 1, k = c & 1;
+    out[4 * b + k] = e ? got : keep;      // r = k: drawn by the even-h lane
+    out[4 * b + 2 + k] = e ? keep : got;  // r = 2 + k: drawn by the odd-h lane
+  }
 }
 
 // One Metropolis chain (Sampler::metropolis_hastings, src/samplers.cpp:21-35):

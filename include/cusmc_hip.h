@@ -63,6 +63,12 @@ typedef struct cusmc_dist cusmc_dist; /* a StatisticalDistribution instance (mu,
 /* ---- library / context ---------------------------------------------------------------- */
 
 const char *cusmc_version(void);
+/* Version of the counter-based RNG contract the draws follow: which Philox block and
+ * which words of it feed which draw.  A seed reproduces a result only under the same contract version.
+ * 2 (round 3): chi-square draws keyed by the component pair -- closed form for nu = 2, 4, pair-shared
+ * Marsaglia-Tsang attempts otherwise; everything else as contract 1.  (The reference has no contract: it
+ * reseeds from std::random_device per call, src/statistics.cc.cpp:231-232, 360-361.) */
+int cusmc_rng_contract(void);
 const char *cusmc_last_error(void);
 /* Number of visible HIP devices (0 when none; never fails). */
 int cusmc_device_count(void);

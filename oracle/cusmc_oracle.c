@@ -342,7 +342,8 @@ ORACLE_API int oracle_logpdf_hoisted(const double *X, long N, long ldx, const do
  *   key     = (seed_lo, seed_hi)
  *   counter = (index, sub, step, domain)
  * domain tags: 1 resampler, 2 proposal normals, 3 chi-square normals, 4 initial normals,
- *              5 chi-square accept/boost uniforms.
+ *              5 chi-square accept/boost uniforms, 6 chi-square closed-form uniforms (contract 2: see
+ *              chi_square_for).
  * ---------------------------------------------------------------------------------------- */
 #define PHILOX_M0 0xD2511F53u
 #define PHILOX_M1 0xCD9E8D57u
@@ -484,43 +485,85 @@ static void normals_for(uint32_t particle, uint32_t step, uint32_t domain, const
   }
 }
 
-/* chi^2_nu = 2 * Gamma(nu/2, 1), Marsaglia-Tsang squeeze with the a<1 boost, the sampler the
- * reference's device helper uses, squeeze included (src/mvt_dist.cu.cpp:20-61; the CPU path uses libstdc++'s
- * chi_squared_distribution, src/statistics.cc.cpp:366,385).  The counter advance is
- * deterministic: attempt m < 63 of (particle, component j) takes its normal from block
- * (particle, j*64+m, step, 3) and its accept-uniform from block (particle, j*64+m, step, 5);
- * the a<1 boost uniform is block (particle, j*64+63, step, 5). */
+/* chi^2_nu draws, RNG CONTRACT 2 (round 3; contract 1 keyed two Philox blocks and a whole Box-Muller pair per
+ * attempt and component and threw the second normal and half of the uniforms away -- 3 to 4.6 x the cost of
+ * the Normal draw on the GPU).  The reference's draws cannot be reproduced by anyone (std::random_device per
+ * call, src/statistics.cc.cpp:360-361; curand_init(dev_seed, ...) with a wall-clock seed on the device path), so
+ * what has to hold is the LAW: chi[j] ~ chi^2_nu, independent over components j and of the normals
+ * (src/statistics.cc.cpp:366, 383-386: `chi[j] = X2(generator)` per component).  Everything is keyed by the
+ * component PAIR p = j / 2, half e = j % 2 -- the unit the proposal normals are keyed by as well:
+ *
+ *   nu == 2 or nu == 4 (exactly)   closed form, no rejection:  chi^2_{2m} = -2 ln(u_1 ... u_m), m = nu / 2.
+ *       ONE block (particle, p, step, 6) per pair; half e takes words (2e, 2e+1):
+ *         m = 1:  u = ((w_2e : w_2e+1) >> 12 + 1/2) 2^-52                       in (0, 1), 52 bits
+ *         m = 2:  u_1 = (w_2e + 1/2) 2^-32,  u_2 = (w_2e+1 + 1/2) 2^-32         in (0, 1), 32 bits each
+ *       (32-bit uniforms at m = 2: the product has 2^64 equally likely values; the largest draw is 91.5 where
+ *       the exact law has 6e-19 beyond it, the smallest 4.7e-10 with 3e-20 below it)
+ *   any other nu   Marsaglia-Tsang as the reference's device helper (src/mvt_dist.cu.cpp:20-61; libstdc++'s
+ *       gamma_distribution behind chi_squared_distribution on the CPU path is the same algorithm), squeeze
+ *       included, a < 1 boost included.  Attempt m < 63 of pair p: block (particle, 64 p + m, step, 3) ->
+ *       Box-Muller -> z0 is half 0's normal, z1 half 1's; block (particle, 64 p + m, step, 5) -> words (2e, 2e+1)
+ *       -> half e's accept uniform u = 1 - u01 in (0, 1].  The two halves walk their attempts independently
+ *       (each stops at its own first accept; what the other half leaves unused is discarded).  a < 1 boost
+ *       uniform: block (particle, 64 p + 63, step, 5), words (2e, 2e+1). */
 static double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, const uint32_t key[2],
                              float nu)
 {
+  const uint32_t p = j >> 1, e = j & 1u;
+  if (nu == 2.0f || nu == 4.0f) {
+    uint32_t ctr[4] = {particle, p, step, 6u}, r[4];
+    oracle_philox4x32_10(ctr, key, r);
+    double P;
+    if (nu == 2.0f) {
+      const uint64_t v = (((uint64_t)r[2 * e] << 32) | r[2 * e + 1]) >> 12;
+      P = ((double)v + 0.5) * 0x1.0p-52;
+    } else {
+      P = fma((double)r[2 * e], 0x1.0p-32, 0x1.0p-33) * fma((double)r[2 * e + 1], 0x1.0p-32, 0x1.0p-33);
+    }
+    return -2.0 * log(P);
+  }
   double a = 0.5 * (double)nu;
   double boost = 1.0;
   if (a < 1.0) {
-    uint32_t ctr[4] = {particle, j * 64u + 63u, step, 5u}, r[4];
+    uint32_t ctr[4] = {particle, p * 64u + 63u, step, 5u}, r[4];
     oracle_philox4x32_10(ctr, key, r);
-    boost = pow(1.0 - u01_53(r[0], r[1]), 1.0 / a);
+    boost = pow(1.0 - u01_53(r[2 * e], r[2 * e + 1]), 1.0 / a);
     a += 1.0;
   }
   double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
   double g = dd; /* value if all 63 attempts reject (probability < 1e-60) */
   for (uint32_t m = 0; m < 63u; ++m) {
-    uint32_t ctr[4] = {particle, j * 64u + m, step, 3u}, r[4];
-    double z0, z1;
+    uint32_t ctr[4] = {particle, p * 64u + m, step, 3u}, r[4];
+    double zz[2];
     oracle_philox4x32_10(ctr, key, r);
-    normal_pair(r, &z0, &z1);
-    double v = 1.0 + c * z0;
+    normal_pair(r, &zz[0], &zz[1]);
+    const double z = zz[e];
+    double v = 1.0 + c * z;
     if (v <= 0.0) continue;
     v = v * v * v;
     ctr[3] = 5u;
     oracle_philox4x32_10(ctr, key, r);
-    double u = 1.0 - u01_53(r[0], r[1]);
-    /* the reference's squeeze (src/mvt_dist.cu.cpp:45), u < 1 - 0.0331 z0^4 as one fixed sequence of roundings
+    double u = 1.0 - u01_53(r[2 * e], r[2 * e + 1]);
+    /* the reference's squeeze (src/mvt_dist.cu.cpp:45), u < 1 - 0.0331 z^4 as one fixed sequence of roundings
      * (the kernels evaluate the same fma: smallops.h chi_squeeze), then its log test (:48) */
-    const double z2 = z0 * z0;
+    const double z2 = z * z;
     if (u < fma(-(0.0331 * z2), z2, 1.0) ||
-        log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) { g = dd * v; break; }
+        log(u) < 0.5 * z * z + dd - dd * v + dd * log(v)) { g = dd * v; break; }
   }
   return 2.0 * g * boost;
+}
+
+ORACLE_API int oracle_rng_contract(void) { return 2; }
+
+/* chi^2 draws of components [0, d) of `count` particles starting at `first` (tests/test_distributions.py holds
+ * them against the exact chi^2_nu law; the kernels never see this) */
+ORACLE_API void oracle_chi_square(double *out, uint32_t first, uint32_t count, int d, float nu, uint64_t seed,
+                                  uint32_t step)
+{
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < count; ++i)
+    for (int j = 0; j < d; ++j) out[(size_t)i * d + j] = chi_square_for(first + i, (uint32_t)j, step, key, nu);
 }
 
 /* One proposal draw given the location m (d) and the square-root factor Q (d x d, dense).

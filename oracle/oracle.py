@@ -188,6 +188,18 @@ def chol_batched(sigma):
     return L, logdet, info
 
 
+def chi_square(count, d, nu, seed=0, step=0, first=0):
+    """The chi^2_nu draws of components 0..d-1 of particles first..first+count-1 (RNG contract 2)."""
+    out = np.empty((count, d), dtype=np.float64)
+    lib().oracle_chi_square(_p(out), C.c_uint32(first), C.c_uint32(count), C.c_int(d), C.c_float(nu),
+                            C.c_uint64(seed), C.c_uint32(step))
+    return out
+
+
+def rng_contract():
+    return int(lib().oracle_rng_contract())
+
+
 def eigen_sqrt(S):
     S = _d(S)
     Q = np.empty_like(S)

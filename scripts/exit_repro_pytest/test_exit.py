@@ -1,10 +1,15 @@
-"""NOT part of the suite (pytest tests/ never collects it).  Round 1 saw `terminate called after throwing an
+"""NOT part of the suite (pytest.ini's testpaths = tests: a bare `pytest` never collects it).  Round 1 saw `terminate called after throwing an
 instance of 'std::bad_variant_access'` when pytest exited after a FAILED gpu test with live handles and device
 tensors in the failing frame (gpurun_out/pytest.txt).  This re-creates that exit on purpose:
     CUSMC_TRACE_TERMINATE=1 python -m pytest scripts/exit_repro_pytest -x -q -p no:cacheprovider
 and the terminate tracer in libcusmc_hip prints the stack that threw, if it happens again."""
 import numpy as np
 import pytest
+
+
+def spd(rng, d):
+    A = rng.standard_normal((d, d))
+    return A @ A.T / d + np.eye(d)
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +30,6 @@ def test_passes_first_with_the_oracle_loaded(cs, oracle):
 def test_fails_with_live_handles(cs, dist, nu):
     import torch
     from cusmc_amd import api
-    from conftest import spd  # (this directory's conftest re-exports the suite's)
     rng = np.random.default_rng(3)
     d, N, B, seed, step = 2, 20000, 10, 5, 3
     G, Q = 0.9 * np.eye(d), 0.3 * np.eye(d)

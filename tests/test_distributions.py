@@ -57,7 +57,8 @@ def check_covariance(draw_q, eigen_sqrt):
 
 def check_student(draw_t):
     """draw_t(count, nu, seed) -> count x 2 draws with mu = 0, Q = I: two INDEPENDENT t_nu marginals (F7)"""
-    for nu in (0.75, 1.5, 3.0, 4.0, 30.0):  # 0.75, 1.5: the a < 1 boost of the gamma sampler (src/mvt_dist.cu.cpp:53-60)
+    # 0.75, 1.5: the a < 1 boost of the gamma sampler (src/mvt_dist.cu.cpp:53-60); 2, 4: RNG contract 2's closed forms
+    for nu in (0.75, 1.5, 2.0, 3.0, 4.0, 30.0):
         X = draw_t(200_000, nu, 13)
         for j in range(2):
             assert ks_p(X[:, j], stats.t(nu)) > P_MIN, (nu, j)
@@ -144,6 +145,24 @@ def test_oracle_student_marginals(oracle):
     check_student(lambda n, nu, seed: oracle.initialize(n, np.zeros(2), np.eye(2), "mvt", nu, seed=seed)[0])
 
 
+def check_chi_square(draw):
+    """draw(count, d, nu, seed) -> count x d chi-square draws: every component chi^2_nu, components independent --
+    in particular the two halves of a component pair, which RNG contract 2 feeds from the same Philox blocks."""
+    for nu in (0.5, 1.0, 2.0, 2.5, 3.0, 4.0, 6.0, 30.0):
+        x = draw(150_000, 5, nu, 23)
+        for j in range(5):
+            assert ks_p(x[:, j], stats.chi2(nu)) > P_MIN, (nu, j)
+        assert ks_p(x[:, 0], stats.chi2(1.04 * nu)) < 1e-4, nu       # (4 % in nu is visible)
+        for i, j in ((0, 1), (2, 3), (1, 2), (3, 4)):                 # pair mates and neighbours across pairs
+            rho = stats.spearmanr(x[:, i], x[:, j]).statistic
+            assert abs(rho) < 0.012, (nu, i, j, rho)
+
+
+def test_oracle_chi_square_law(oracle):
+    assert oracle.rng_contract() == 2
+    check_chi_square(lambda n, d, nu, seed: oracle.chi_square(n, d, nu, seed=seed, step=3))
+
+
 def test_oracle_resampler_stationary_law(oracle):
     check_resampler(lambda w, B, seed: oracle.metropolis(w, B, seed))
 
@@ -198,17 +217,40 @@ def test_gpu_student_marginals(cs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nu", [4.0, 2.0, 3.0])
 @pytest.mark.parametrize("d", [16, 64, 256])
-def test_gpu_student_marginals_matrix_core_kernels(cs, d):
+def test_gpu_student_marginals_matrix_core_kernels(cs, d, nu):
     """The same law out of the matrix-core proposal kernels (d = 16, 64: propagate_mfma_kernel; d = 256:
-    propagate_wide_kernel): Q = I, two of the d components tested per kernel, chi-square per component."""
-    D = cs.MultiVariateTStudentDistribution(np.zeros(d), np.eye(d), 4.0)
-    X = D.sample(np.eye(d), count=100_000, seed=17, step=4)
+    propagate_wide_kernel): two of the d components tested per kernel, chi-square per component -- nu = 4, 2: the
+    closed forms, 3: Marsaglia-Tsang, all three through the lane exchange of the C layout (chi_square_clayout).
+    Q is block diagonal with a rotation in every 2 x 2 block (Q Q^T = I, but NOT diagonal: a diagonal Q would
+    take propagate_diag_kernel)."""
+    c, s = np.cos(0.3), np.sin(0.3)
+    Q = np.kron(np.eye(d // 2), np.array([[c, -s], [s, c]]))
+    D = cs.MultiVariateTStudentDistribution(np.zeros(d), np.eye(d), nu)
+    X = D.sample(Q, count=100_000, seed=17, step=4)
     D.close()
-    for j in (0, d - 1):
-        assert ks_p(X[:, j], stats.t(4.0)) > P_MIN, j
+    for j in (0, 1, d - 1):
+        assert ks_p(X[:, j], stats.t(nu)) > P_MIN, j
     assert abs(stats.spearmanr(np.abs(X[:, 0]), np.abs(X[:, 1])).statistic) < 0.012
+    assert abs(stats.spearmanr(np.abs(X[:, 0]), np.abs(X[:, 4])).statistic) < 0.012
     assert ks_p(X[:, d // 2], stats.norm()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_chi_square_law_through_the_draws(cs):
+    """chi^2 itself, recovered from Student-t draws with Q = I, mu = 0 and the SAME seed's Normal draws: the
+    contract keys the normals identically for both kinds, so x_t / x_n = sqrt(nu / chi2) component by component."""
+    for nu in (2.0, 4.0, 2.5, 0.5):
+        T = cs.MultiVariateTStudentDistribution(np.zeros(6), np.eye(6), nu)
+        Nn = cs.MultiVariateNormalDistribution(np.zeros(6), np.eye(6))
+        xt = T.sample(np.eye(6), count=150_000, seed=29, step=2)
+        xn = Nn.sample(np.eye(6), count=150_000, seed=29, step=2)
+        T.close(); Nn.close()
+        chi = nu * (xn / xt) ** 2
+        for j in range(6):
+            assert ks_p(chi[:, j], stats.chi2(nu)) > P_MIN, (nu, j)
+        assert abs(stats.spearmanr(chi[:, 0], chi[:, 1]).statistic) < 0.012
 
 
 @pytest.mark.gpu
