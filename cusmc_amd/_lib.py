@@ -38,10 +38,13 @@ SYMBOLS = [
     ("cusmc_dist_pdf_host", _i, [_vp, _vp, _i64, _i64, _vp, _i, _vp]),
     ("cusmc_dist_reweight_dev", _i, [_vp, _vp, _i64, _i64, _vp, _vp, _i, _vp]),
     ("cusmc_dist_reweight_host", _i, [_vp, _vp, _i64, _i64, _vp, _vp, _i, _vp]),
+    ("cusmc_dist_pdf_multi_host", _i, [_vp, C.POINTER(_i), _i, _vp, _i64, _i64, _vp, _i, _vp]),
+    ("cusmc_dist_reweight_multi_host", _i, [_vp, C.POINTER(_i), _i, _vp, _i64, _i64, _vp, _vp, _i, _vp]),
     ("cusmc_metropolis_dev", _i, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _vp]),
     ("cusmc_metropolis_host", _i, [_vp, _vp, _u32, _u32, _u64, _u32, _vp]),
     ("cusmc_metropolis_log_dev", _i, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _vp]),
     ("cusmc_metropolis_log_host", _i, [_vp, _vp, _u32, _u32, _u64, _u32, _vp]),
+    ("cusmc_metropolis_multi_host", _i, [C.POINTER(_i), _i, _vp, _u32, _u32, _u64, _u32, _i, _vp]),
     ("cusmc_propagate_dev", _i, [_vp, _i, _f, _vp, _vp, _u32, _i, _vp, _vp, _d, _u64, _u32, _u32,
                                  _u32, _vp]),
     ("cusmc_initialize_dev", _i, [_vp, _i, _f, _vp, _vp, _i, _d, _u64, _u32, _u32, _vp]),

@@ -221,27 +221,39 @@ class _Distribution:
         return self.sigma.copy()  # sic: the reference returns sigma (statistics.cc.cpp:221)
 
     # -- batched interface (host buffers) -----------------------------------------------------
-    def pdf_batch(self, X, F=None, log=True):
-        """out[i] = (log) p(X[i]; F mu, Sigma): pdf(y, F) over N x d rows."""
+    def pdf_batch(self, X, F=None, log=True, devices=None):
+        """out[i] = (log) p(X[i]; F mu, Sigma): pdf(y, F) over N x d rows.
+        devices = [0, 1, ...]: the rows sharded over those GPUs below the C ABI (cusmc_dist_pdf_multi_host; the
+        environment variable CUSMC_DEVICES does the same for callers that cannot pass the list)."""
         X = _f64(X)
         if X.ndim != 2 or X.shape[1] != self.d:
             raise ValueError("X must be N x %d" % self.d)
         Fm = None if F is None else self._square(F, "F")
         out = np.empty(X.shape[0])
-        check(_lib.lib().cusmc_dist_pdf_host(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(Fm),
-                                             OUT_LOG if log else OUT_DENSITY, _ptr(out)))
+        flags = OUT_LOG if log else OUT_DENSITY
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(v) for v in devices])
+            check(_lib.lib().cusmc_dist_pdf_multi_host(self._h, devs, len(devices), _ptr(X), X.shape[0], X.shape[1],
+                                                       _ptr(Fm), flags, _ptr(out)))
+        else:
+            check(_lib.lib().cusmc_dist_pdf_host(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(Fm), flags, _ptr(out)))
         return out
 
-    def reweight(self, X, y, F, log=True):
-        """out[i] = (log) p(y - F X[i]; 0, Sigma): reweight_G (src/mcmc.cpp:185-215)."""
+    def reweight(self, X, y, F, log=True, devices=None):
+        """out[i] = (log) p(y - F X[i]; 0, Sigma): reweight_G (src/mcmc.cpp:185-215).  devices: as pdf_batch."""
         X, y = _f64(X), _f64(y).reshape(-1)
         if X.ndim != 2 or X.shape[1] != self.d or y.shape[0] != self.d:
             raise ValueError("X must be N x %d and y of length %d" % (self.d, self.d))
         Fm = None if F is None else self._square(F, "F")
         out = np.empty(X.shape[0])
-        check(_lib.lib().cusmc_dist_reweight_host(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(y),
-                                                  _ptr(Fm), OUT_LOG if log else OUT_DENSITY,
-                                                  _ptr(out)))
+        flags = OUT_LOG if log else OUT_DENSITY
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(v) for v in devices])
+            check(_lib.lib().cusmc_dist_reweight_multi_host(self._h, devs, len(devices), _ptr(X), X.shape[0], X.shape[1],
+                                                            _ptr(y), _ptr(Fm), flags, _ptr(out)))
+        else:
+            check(_lib.lib().cusmc_dist_reweight_host(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(y), _ptr(Fm), flags,
+                                                      _ptr(out)))
         return out
 
     # -- batched interface (device-resident torch tensors) -----------------------------------
@@ -365,20 +377,26 @@ class Sampler:
     """inst/include/samplers.hpp:7-18."""
 
     @staticmethod
-    def metropolis_hastings(w, N=None, t=1, B=10, seed=0, ctx=None):
+    def metropolis_hastings(w, N=None, t=1, B=10, seed=0, ctx=None, devices=None):
         """Sampler::metropolis_hastings(a_t, w_t, N, t, B) -- src/samplers.cpp:7-36.  Takes the
-        weight vector w_t[t-1] and returns the row a_t[t*N : (t+1)*N] (uint32, 0-based)."""
-        ctx = ctx or default_context()
+        weight vector w_t[t-1] and returns the row a_t[t*N : (t+1)*N] (uint32, 0-based).
+        devices = [0, 1, ...]: the chains sharded over those GPUs below the C ABI (cusmc_metropolis_multi_host;
+        CUSMC_DEVICES in the environment does the same), ancestors bit-identical to one device."""
         w = _f64(w).reshape(-1)
         N = w.shape[0] if N is None else int(N)
         if N > w.shape[0]:
             raise ValueError("N = %d exceeds the %d weights given" % (N, w.shape[0]))
         a = np.empty(N, dtype=np.uint32)
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(v) for v in devices])
+            check(_lib.lib().cusmc_metropolis_multi_host(devs, len(devices), _ptr(w), N, int(B), int(seed), int(t), 0, _ptr(a)))
+            return a
+        ctx = ctx or default_context()
         check(_lib.lib().cusmc_metropolis_host(ctx._h, _ptr(w), N, int(B), int(seed), int(t), _ptr(a)))
         return a
 
     @staticmethod
-    def metropolis_hastings_log(logw, N=None, t=1, B=10, seed=None, ctx=None):
+    def metropolis_hastings_log(logw, N=None, t=1, B=10, seed=None, ctx=None, devices=None):
         """The chain over LOG-weights (accept iff u <= exp(logw[j] - logw[k])): the resampler for
         log-densities, which do not underflow at large d the way the reference's densities do."""
         logw = _f64(logw).reshape(-1)
@@ -387,8 +405,12 @@ class Sampler:
             seed = _next_key()
         if N > logw.shape[0]:
             raise ValueError("N = %d exceeds the %d log-weights given" % (N, logw.shape[0]))
-        ctx = ctx or default_context()
         a = np.empty(N, dtype=np.uint32)
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(v) for v in devices])
+            check(_lib.lib().cusmc_metropolis_multi_host(devs, len(devices), _ptr(logw), N, int(B), int(seed), int(t), 1, _ptr(a)))
+            return a
+        ctx = ctx or default_context()
         check(_lib.lib().cusmc_metropolis_log_host(ctx._h, _ptr(logw), N, int(B), int(seed), int(t), _ptr(a)))
         return a
 

@@ -123,6 +123,7 @@ struct cusmc_dist;
 struct cusmc_ctx {
   int device = 0;
   int num_cus = 0;
+  bool propagate_rows = false;  // CUSMC_PROPAGATE_ROWS at creation: round 1's one-workgroup-per-particle proposal kernel above d = 128 (A/B timing)
   hipStream_t stream = nullptr;
   DevBuf scratch[6];  // host-pointer entry points: X, out, w, a, small matrices
   StagingRing ring;  // pinned staging for small parameter uploads
@@ -148,6 +149,8 @@ struct cusmc_dist {
   float nu = 0.f;
   double logdet = 0.0, lognorm = 0.0;
   std::vector<double> mu, W;  // W = L^-1, row-major lower triangular
+  std::vector<double> sigma;  // as given: what a replica on another device is created from
+  std::vector<cusmc_dist *> replicas;  // slot r of a device list -> this distribution on that slot's context (multi-device host paths)
   // device images of the current (M, shift, bias) plan
   DevBuf frags, Mdev, shift, bias;
   // what is currently uploaded, to skip redundant uploads in time loops
@@ -355,6 +358,130 @@ int plan_affine(cusmc_dist *dist, const double *y, const double *F)
   return install_plan(dist, 2, rotate, cached ? dist->hostM : M, F, shift, bias);
 }
 
+
+// ---- several GPUs below the C ABI: shared pieces ----------------------------------------------------------------
+//
+// The host-pointer entry points (what the R glue binds) shard over the devices named by CUSMC_DEVICES="0,1,.." or by
+// the *_multi_host entry points: contiguous shards, one host thread per shard -- a pageable hipMemcpyAsync holds
+// its calling thread, so only threads put several PCIe links to work at once --, each on a context and stream the
+// LIBRARY owns (slot r of the list; created on first use and kept for the life of the process: nothing to
+// finalize in the wrong order at exit).  A device may be listed more than once (how a one-GPU box rehearses the
+// path).  One multi-device call at a time (the pool is locked for the duration of a call).
+struct PoolSlot {
+  cusmc_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;
+};
+std::mutex g_pool_mutex;
+std::vector<PoolSlot> g_pool;
+
+// "0,1,2" -> {0,1,2}; unset or empty -> {}
+int env_devices(std::vector<int> &devs)
+{
+  devs.clear();
+  const char *env = getenv("CUSMC_DEVICES");
+  if (!env) return CUSMC_OK;
+  for (const char *c = env; *c;) {
+    char *end = nullptr;
+    const long v = strtol(c, &end, 10);
+    if (end == c || (*end && *end != ','))
+      return fail(CUSMC_EINVAL, "CUSMC_DEVICES='%s' is not a comma-separated list of device numbers", env);
+    devs.push_back((int)v);
+    c = *end == ',' ? end + 1 : end;
+  }
+  return CUSMC_OK;
+}
+
+int check_devices(const int *devices, int ndev)
+{
+  if (!devices || ndev < 1) return fail(CUSMC_EINVAL, "empty device list");
+  if (ndev > cusmc::kMaxShards) return fail(CUSMC_ERANGE, "%d devices exceed the %d supported", ndev, cusmc::kMaxShards);
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible == 0)
+    return fail(CUSMC_ENODEVICE, "no HIP device visible: libcusmc_hip has no CPU fallback");
+  for (int r = 0; r < ndev; ++r)
+    if (devices[r] < 0 || devices[r] >= visible)
+      return fail(CUSMC_EINVAL, "device %d out of range (%d visible)", devices[r], visible);
+  return CUSMC_OK;
+}
+
+// slot r's context on `device` (g_pool_mutex held by the caller)
+int pool_ctx(int slot, int device, cusmc_ctx **out)
+{
+  if ((int)g_pool.size() <= slot) g_pool.resize(slot + 1);
+  PoolSlot &ps = g_pool[slot];
+  if (ps.ctx && ps.ctx->device != device) {  // the list changed between calls
+    ps.ctx->stream = nullptr;
+    cusmc_ctx_destroy(ps.ctx);
+    if (ps.stream) (void)hipStreamDestroy(ps.stream);
+    ps = PoolSlot();
+  }
+  if (!ps.ctx) {
+    if (int rc = cusmc_ctx_create(device, &ps.ctx)) return rc;
+    const hipError_t e = hipStreamCreateWithFlags(&ps.stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      cusmc_ctx_destroy(ps.ctx);
+      ps = PoolSlot();
+      return fail(CUSMC_EHIP, "%s creating a stream on device %d", hipGetErrorString(e), device);
+    }
+    ps.ctx->stream = ps.stream;
+  }
+  *out = ps.ctx;
+  return CUSMC_OK;
+}
+
+// the calling thread's current device, put back when a multi-device entry point returns
+struct DeviceRestore {
+  int saved = -1;
+  DeviceRestore() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+  ~DeviceRestore() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
+// contiguous shards of n items over `parts`: the first n % parts shards take one more
+void shard_range(uint64_t n, int parts, int r, uint64_t *first, uint64_t *count)
+{
+  const uint64_t base = n / (uint64_t)parts, extra = n % (uint64_t)parts;
+  *first = base * (uint64_t)r + ((uint64_t)r < extra ? (uint64_t)r : extra);
+  *count = base + ((uint64_t)r < extra ? 1u : 0u);
+}
+
+// fn(r) -> status for r < n, shards that do NOT wait for each other: rank 0 on the calling thread, the others on
+// threads of their own; a rank whose thread cannot be started runs on the caller afterwards; nothing thrown
+// inside a rank leaves it (the ABI promises that no exception crosses it).  Returns the first failure and its text.
+template <class F>
+int run_sharded(int n, F &&fn)
+{
+  std::vector<int> rc(n, CUSMC_OK);
+  std::vector<std::string> err(n);
+  auto body = [&](int r) {
+    try {
+      rc[r] = fn(r);
+    } catch (const std::exception &e) {
+      rc[r] = fail(CUSMC_EINVAL, "exception in shard %d: %s", r, e.what());
+    } catch (...) {
+      rc[r] = fail(CUSMC_EINVAL, "exception in shard %d", r);
+    }
+    if (rc[r]) err[r] = g_last_error;
+  };
+  std::vector<std::thread> threads;
+  std::vector<int> inline_ranks;
+  for (int r = 1; r < n; ++r) {
+    try {
+      threads.emplace_back(body, r);
+    } catch (...) {
+      inline_ranks.push_back(r);
+    }
+  }
+  body(0);
+  for (int r : inline_ranks) body(r);
+  for (auto &th : threads) th.join();
+  for (int r = 0; r < n; ++r)
+    if (rc[r]) {
+      g_last_error = err[r];
+      return rc[r];
+    }
+  return CUSMC_OK;
+}
+
 }  // namespace
 
 // ---- library / context ----------------------------------------------------------------------
@@ -422,6 +549,7 @@ CUSMC_EXPORT int cusmc_ctx_create(int device, cusmc_ctx **out)
   if (!ctx) return fail(CUSMC_EINVAL, "out of host memory");
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
+  ctx->propagate_rows = getenv("CUSMC_PROPAGATE_ROWS") != nullptr;
   *out = ctx;
   return CUSMC_OK;
 }
@@ -510,6 +638,7 @@ CUSMC_EXPORT int cusmc_dist_create(cusmc_ctx *ctx, int kind, const double *mu, c
   dist->d = d;
   dist->nu = kind == CUSMC_MVT ? nu : 0.f;
   if (mu) dist->mu.assign(mu, mu + d); else dist->mu.assign(d, 0.0);
+  dist->sigma.assign(sigma, sigma + (size_t)d * d);
   cusmc::la::lower_inverse(L, d, dist->W);
   double logdet = 0.0;
   for (int i = 0; i < d; ++i) logdet += 2.0 * std::log(L[(size_t)i * d + i]);
@@ -533,6 +662,8 @@ CUSMC_EXPORT int cusmc_dist_create(cusmc_ctx *ctx, int kind, const double *mu, c
 CUSMC_EXPORT int cusmc_dist_destroy(cusmc_dist *dist)
 {
   if (!dist) return CUSMC_OK;
+  for (cusmc_dist *rep : dist->replicas) cusmc_dist_destroy(rep);
+  dist->replicas.clear();
   if (cusmc_ctx *ctx = dist->ctx) {  // (null: the context went first and took the device buffers with it)
     try {
       (void)hipSetDevice(ctx->device);
@@ -606,18 +737,75 @@ int host_density(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx, cons
   return CUSMC_OK;
 }
 
+// Rows sharded over a device list: shard r = rows [first_r, first_r + count_r) on slot r's context, through a
+// replica of the distribution there (factored and uploaded once per slot, kept with the handle).  Every row's
+// value is the single-device value bit for bit (a particle's result does not depend on its tile mates).
+int multi_density(cusmc_dist *dist, const int *devices, int ndev, const double *X, int64_t N, int64_t ldx,
+                  const double *y, const double *F, int flags, double *out, bool affine)
+{
+  if (int rc = check_batch(dist, X, N, ldx, out)) return rc;
+  if (int rc = check_devices(devices, ndev)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (affine && !y) return fail(CUSMC_EINVAL, "null y");
+  // (a shard below ~1000 rows costs more in threads and launches than it saves)
+  const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(ndev, N / 1024));
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  DeviceRestore restore;
+  if ((int)dist->replicas.size() < parts) dist->replicas.resize(parts, nullptr);
+  for (int r = 0; r < parts; ++r) {
+    cusmc_ctx *ctx = nullptr;
+    if (int rc = pool_ctx(r, devices[r], &ctx)) return rc;
+    cusmc_dist *&rep = dist->replicas[r];
+    if (rep && rep->ctx != ctx) {  // the slot's context was rebuilt (another device list): start over
+      cusmc_dist_destroy(rep);
+      rep = nullptr;
+    }
+    if (!rep)
+      if (int rc = cusmc_dist_create(ctx, dist->kind, dist->mu.data(), dist->sigma.data(), dist->d, dist->nu, &rep)) return rc;
+  }
+  return run_sharded(parts, [&](int r) {
+    uint64_t first, count;
+    shard_range((uint64_t)N, parts, r, &first, &count);
+    return host_density(dist->replicas[r], X + first * (uint64_t)ldx, (int64_t)count, ldx, y, F, flags, out + first, affine);
+  });
+}
+
+// CUSMC_DEVICES in the environment: the host-pointer call goes to that device list (one entry: that device)
+int routed_density(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx, const double *y, const double *F, int flags,
+                   double *out, bool affine)
+{
+  std::vector<int> devs;
+  if (int rc = env_devices(devs)) return rc;
+  if (!devs.empty() && dist && dist->ctx && !(devs.size() == 1 && devs[0] == dist->ctx->device))
+    return multi_density(dist, devs.data(), (int)devs.size(), X, N, ldx, y, F, flags, out, affine);
+  return host_density(dist, X, N, ldx, y, F, flags, out, affine);
+}
+
 }  // namespace
 
 CUSMC_EXPORT int cusmc_dist_pdf_host(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx,
                                      const double *F, int flags, double *out)
 {
-  return host_density(dist, X, N, ldx, nullptr, F, flags, out, false);
+  return routed_density(dist, X, N, ldx, nullptr, F, flags, out, false);
 }
 
 CUSMC_EXPORT int cusmc_dist_reweight_host(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx,
                                           const double *y, const double *F, int flags, double *out)
 {
-  return host_density(dist, X, N, ldx, y, F, flags, out, true);
+  return routed_density(dist, X, N, ldx, y, F, flags, out, true);
+}
+
+CUSMC_EXPORT int cusmc_dist_pdf_multi_host(cusmc_dist *dist, const int *devices, int ndev, const double *X, int64_t N,
+                                           int64_t ldx, const double *F, int flags, double *out)
+{
+  return multi_density(dist, devices, ndev, X, N, ldx, nullptr, F, flags, out, false);
+}
+
+CUSMC_EXPORT int cusmc_dist_reweight_multi_host(cusmc_dist *dist, const int *devices, int ndev, const double *X,
+                                                int64_t N, int64_t ldx, const double *y, const double *F, int flags,
+                                                double *out)
+{
+  return multi_density(dist, devices, ndev, X, N, ldx, y, F, flags, out, true);
 }
 
 // ---- resampler ------------------------------------------------------------------------------
@@ -640,21 +828,76 @@ CUSMC_EXPORT int cusmc_metropolis_dev(cusmc_ctx *ctx, const double *w_dev, uint3
   return CUSMC_OK;
 }
 
-CUSMC_EXPORT int cusmc_metropolis_host(cusmc_ctx *ctx, const double *w, uint32_t N, uint32_t B,
-                                       uint64_t seed, uint32_t step, uint32_t *a)
+namespace {
+
+// one device: upload w, run chains [first, first + count), bring their ancestors back
+int host_metropolis(cusmc_ctx *ctx, const double *w, uint32_t N, uint32_t B, uint64_t seed, uint32_t step, bool logw,
+                    uint32_t first, uint32_t count, uint32_t *a)
+{
+  if (int rc = activate(ctx)) return rc;
+  if (count == 0) return CUSMC_OK;
+  if (int rc = ctx->scratch[2].reserve((size_t)N * 8)) return rc;
+  if (int rc = ctx->scratch[3].reserve((size_t)count * 4)) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->scratch[2].p, w, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = logw ? cusmc_metropolis_log_dev(ctx, (const double *)ctx->scratch[2].p, N, B, seed, step, first, count,
+                                               (uint32_t *)ctx->scratch[3].p)
+                    : cusmc_metropolis_dev(ctx, (const double *)ctx->scratch[2].p, N, B, seed, step, first, count,
+                                           (uint32_t *)ctx->scratch[3].p))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(a, ctx->scratch[3].p, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSMC_OK;
+}
+
+// Chains sharded over a device list (BASELINE configs[3]: "chains sharded over 8 x MI355X"): every device takes the
+// whole weight vector (8 N bytes over its own PCIe link) and runs chains [first_r, first_r + count_r); the draws
+// are keyed by the global chain index, so the ancestors are the single-device ones bit for bit.
+int multi_metropolis(const int *devices, int ndev, const double *w, uint32_t N, uint32_t B, uint64_t seed, uint32_t step,
+                     bool logw, uint32_t *a)
+{
+  if (int rc = check_devices(devices, ndev)) return rc;
+  if (N == 0) return CUSMC_OK;
+  if (!w || !a) return fail(CUSMC_EINVAL, "null weight or ancestor pointer");
+  // (a shard is worth its upload of the whole weight vector only with enough chain steps behind it)
+  const uint64_t work = (uint64_t)N * B;
+  const int parts = (int)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)ndev, (uint64_t)N, work / 100000u}));
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  DeviceRestore restore;
+  std::vector<cusmc_ctx *> ctxs(parts, nullptr);
+  for (int r = 0; r < parts; ++r)
+    if (int rc = pool_ctx(r, devices[r], &ctxs[r])) return rc;
+  return run_sharded(parts, [&](int r) {
+    uint64_t first, count;
+    shard_range(N, parts, r, &first, &count);
+    return host_metropolis(ctxs[r], w, N, B, seed, step, logw, (uint32_t)first, (uint32_t)count, a + first);
+  });
+}
+
+int routed_metropolis(cusmc_ctx *ctx, const double *w, uint32_t N, uint32_t B, uint64_t seed, uint32_t step, bool logw,
+                      uint32_t *a)
 {
   if (int rc = activate(ctx)) return rc;
   if (N == 0) return CUSMC_OK;
   if (!w || !a) return fail(CUSMC_EINVAL, "null weight or ancestor pointer");
-  if (int rc = ctx->scratch[2].reserve((size_t)N * 8)) return rc;
-  if (int rc = ctx->scratch[3].reserve((size_t)N * 4)) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->scratch[2].p, w, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
-  if (int rc = cusmc_metropolis_dev(ctx, (const double *)ctx->scratch[2].p, N, B, seed, step, 0, N,
-                                    (uint32_t *)ctx->scratch[3].p))
-    return rc;
-  HIP_TRY(hipMemcpyAsync(a, ctx->scratch[3].p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CUSMC_OK;
+  std::vector<int> devs;
+  if (int rc = env_devices(devs)) return rc;
+  if (!devs.empty() && !(devs.size() == 1 && devs[0] == ctx->device))
+    return multi_metropolis(devs.data(), (int)devs.size(), w, N, B, seed, step, logw, a);
+  return host_metropolis(ctx, w, N, B, seed, step, logw, 0, N, a);
+}
+
+}  // namespace
+
+CUSMC_EXPORT int cusmc_metropolis_host(cusmc_ctx *ctx, const double *w, uint32_t N, uint32_t B,
+                                       uint64_t seed, uint32_t step, uint32_t *a)
+{
+  return routed_metropolis(ctx, w, N, B, seed, step, false, a);
+}
+
+CUSMC_EXPORT int cusmc_metropolis_multi_host(const int *devices, int ndev, const double *w, uint32_t N, uint32_t B,
+                                             uint64_t seed, uint32_t step, int log_weights, uint32_t *a)
+{
+  return multi_metropolis(devices, ndev, w, N, B, seed, step, log_weights != 0, a);
 }
 
 CUSMC_EXPORT int cusmc_metropolis_log_dev(cusmc_ctx *ctx, const double *logw_dev, uint32_t N, uint32_t B,
@@ -672,18 +915,7 @@ CUSMC_EXPORT int cusmc_metropolis_log_dev(cusmc_ctx *ctx, const double *logw_dev
 CUSMC_EXPORT int cusmc_metropolis_log_host(cusmc_ctx *ctx, const double *logw, uint32_t N, uint32_t B,
                                            uint64_t seed, uint32_t step, uint32_t *a)
 {
-  if (int rc = activate(ctx)) return rc;
-  if (N == 0) return CUSMC_OK;
-  if (!logw || !a) return fail(CUSMC_EINVAL, "null weight or ancestor pointer");
-  if (int rc = ctx->scratch[2].reserve((size_t)N * 8)) return rc;
-  if (int rc = ctx->scratch[3].reserve((size_t)N * 4)) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->scratch[2].p, logw, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
-  if (int rc = cusmc_metropolis_log_dev(ctx, (const double *)ctx->scratch[2].p, N, B, seed, step, 0, N,
-                                        (uint32_t *)ctx->scratch[3].p))
-    return rc;
-  HIP_TRY(hipMemcpyAsync(a, ctx->scratch[3].p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CUSMC_OK;
+  return routed_metropolis(ctx, logw, N, B, seed, step, true, a);
 }
 
 // ---- proposal draws -------------------------------------------------------------------------
@@ -772,8 +1004,8 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
                                          count, X_out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
-  // (CUSMC_PROPAGATE_ROWS=1: round 1's one-workgroup-per-particle kernel instead, for A/B timing)
-  if (cusmc::propagate_mfma_wide_supported(d, X_prev_dev, X_out_dev) && !getenv("CUSMC_PROPAGATE_ROWS")) {
+  // (CUSMC_PROPAGATE_ROWS=1 when the context was created: round 1's one-workgroup-per-particle kernel instead, for A/B timing)
+  if (cusmc::propagate_mfma_wide_supported(d, X_prev_dev, X_out_dev) && !ctx->propagate_rows) {
     // 128 < d <= 256: matrix cores with the output blocks split over the waves (kernels/propagate_mfma_wide.hip).
     // device image: [frags(Q) | frags(G) or diag(G) or m0], factors zero-padded to 16*ceil(d/16)
     const int nb = (d + 15) / 16, dp = 16 * nb;
@@ -1037,7 +1269,8 @@ int pf_step_prepare(cusmc_dist *obs, const double *G, const double *Q, const dou
 int pf_step_launch(cusmc_dist *obs, int kind, float nu, const double *w_prev_dev, const double *X_prev_dev,
                    uint32_t N, uint32_t B, double scale, uint64_t seed, uint32_t step, uint32_t first,
                    uint32_t count, uint32_t *a_out_dev, double *X_out_dev, double *w_out_dev, int flags,
-                   const double *shift_dev, const double *bias_dev)
+                   const double *shift_dev, const double *bias_dev, const cusmc::ShardStep *sharded = nullptr,
+                   const uint32_t *whi_prev_dev = nullptr)
 {
   cusmc_ctx *ctx = obs->ctx;
   const int d = obs->d;
@@ -1045,13 +1278,17 @@ int pf_step_launch(cusmc_dist *obs, int kind, float nu, const double *w_prev_dev
   const double *base = (const double *)ctx->step_mats.p;
   const uint32_t *whi = nullptr;
   if (cusmc::metropolis_wants_hiwords(N) && B > 1) {
-    if (int rc = ctx->whi.reserve((size_t)N * 4)) return rc;
-    HIP_TRY(cusmc::launch_hiwords(w_prev_dev, N, (uint32_t *)ctx->whi.p, ctx->num_cus, ctx->stream));
-    whi = (const uint32_t *)ctx->whi.p;
+    if (sharded) {  // (the sharded step keeps the table itself: every shard's kernel writes its part of it)
+      whi = whi_prev_dev;
+    } else {
+      if (int rc = ctx->whi.reserve((size_t)N * 4)) return rc;
+      HIP_TRY(cusmc::launch_hiwords(w_prev_dev, N, (uint32_t *)ctx->whi.p, ctx->num_cus, ctx->stream));
+      whi = (const uint32_t *)ctx->whi.p;
+    }
   }
   HIP_TRY(cusmc::launch_pf_step(kind, nu, w_prev_dev, whi, X_prev_dev, N, d, B, base + dd, base, scale, obs->plan_tri,
                                 (const double *)obs->Mdev.p, shift_dev, bias_dev, make_epilogue(obs, flags), seed,
-                                step, first, count, a_out_dev, X_out_dev, w_out_dev, ctx->num_cus, ctx->stream));
+                                step, first, count, a_out_dev, X_out_dev, w_out_dev, ctx->num_cus, ctx->stream, sharded));
   return CUSMC_OK;
 }
 
@@ -1114,30 +1351,57 @@ void prefault_async(std::vector<std::thread> &pool, void *p, size_t bytes, unsig
 
 // ---- the filter -----------------------------------------------------------------------------
 
-CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T,
-                                   const double *m0, const double *C0, const double *F,
-                                   const double *G, const double *V, const double *W, float df,
-                                   const char *resampler, const char *distribution, uint32_t B,
-                                   double scale, uint64_t seed, double *X_out, double *w_out,
-                                   uint32_t *a_out)
+namespace {
+
+// All of Y is known when a filter starts, so every step's observation vector -- the shift y_t (F = I) or the bias
+// W y_t, rotated by Q^T when the general-F plan is (plan_affine) -- goes up in ONE table and the time loop is
+// launches only: for a small filter the per-step uploads (two 16..2048-byte copies in the stream) would cost
+// more than the launches.  Same values as the per-step plan, bit for bit.  Installs the plan for y_1 (and, for
+// the fused step, the [Q | G] image); `host` must stay alive until the upload has run.
+struct ObsTable {
+  std::vector<double> host;
+  DevBuf dev;
+  bool centred = true;
+  size_t row = 0;
+  const double *shift(const cusmc_dist *obs, uint32_t t) const { return centred ? (const double *)dev.p + (size_t)t * row : (const double *)obs->shift.p; }
+  const double *bias(const cusmc_dist *obs, uint32_t t) const { return centred ? (const double *)obs->bias.p : (const double *)dev.p + (size_t)t * row; }
+};
+int pf_obs_table(cusmc_dist *obs, bool fused, const double *G, const double *Qw, const double *Y, uint32_t T, const double *F,
+                 ObsTable &tab)
+{
+  cusmc_ctx *ctx = obs->ctx;
+  const int d = obs->d;
+  if (int rc = fused ? pf_step_prepare(obs, G, Qw, Y + d, F) : plan_affine(obs, Y + d, F)) return rc;
+  tab.centred = obs->plan == 1;
+  tab.row = (size_t)((d + 63) / 64) * 64;  // the matrix-core kernels stage 16*NB entries
+  tab.host.assign((size_t)T * tab.row, 0.0);
+  std::vector<double> b, rb;
+  for (uint32_t t = 1; t < T; ++t) {
+    const double *y = Y + (size_t)t * d;
+    double *dst = tab.host.data() + (size_t)t * tab.row;
+    if (tab.centred) {
+      std::copy(y, y + d, dst);
+    } else {
+      cusmc::la::matvec(obs->W.data(), y, d, b);
+      if (!obs->plan_Qt.empty()) {
+        cusmc::la::matvec(obs->plan_Qt.data(), b.data(), d, rb);
+        b.swap(rb);
+      }
+      std::copy(b.begin(), b.end(), dst);
+    }
+  }
+  if (int rc = tab.dev.reserve((size_t)T * tab.row * 8)) return rc;
+  HIP_TRY(hipMemcpyAsync(tab.dev.p, tab.host.data(), (size_t)T * tab.row * 8, hipMemcpyHostToDevice, ctx->stream));
+  return CUSMC_OK;
+}
+
+// the whole filter on ONE device (the environment is not consulted here)
+int pf_run_single(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T, const double *m0, const double *C0,
+                  const double *F, const double *G, const double *V, const double *W, float df, const char *resampler,
+                  const char *distribution, uint32_t B, double scale, uint64_t seed, double *X_out, double *w_out,
+                  uint32_t *a_out)
 {
   if (int rc = activate(ctx)) return rc;
-  // CUSMC_DEVICES="0,1,2,3": the same call shards the particles over those GPUs (SURVEY.md section 5), so
-  // that callers bound to this entry point -- the R package's run() -- use the node without a new argument
-  if (const char *env = getenv("CUSMC_DEVICES")) {
-    std::vector<int> devs;
-    for (const char *c = env; *c;) {
-      char *end = nullptr;
-      const long v = strtol(c, &end, 10);
-      if (end == c) return fail(CUSMC_EINVAL, "CUSMC_DEVICES='%s' is not a comma-separated list of device numbers", env);
-      devs.push_back((int)v);
-      c = *end == ',' ? end + 1 : end;
-      if (*end && *end != ',') return fail(CUSMC_EINVAL, "CUSMC_DEVICES='%s' is not a comma-separated list of device numbers", env);
-    }
-    if (devs.size() > 1)
-      return cusmc_pf_run_multi_host(devs.data(), (int)devs.size(), Y, N, d, T, m0, C0, F, G, V, W, df, resampler,
-                                     distribution, B, scale, seed, X_out, w_out, a_out);
-  }
   // validate the option strings BEFORE any work: the reference default-constructs an empty
   // std::function for an unknown key and throws bad_function_call mid-run (mcmc.cpp:269-272)
   if (!resampler || strcmp(resampler, "metropolis") != 0)
@@ -1166,8 +1430,8 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   if (int rc = cusmc_dist_create(ctx, kind, nullptr, V, d, df, &obs)) return rc;
 
   const size_t slice = (size_t)N * d;
-  DevBuf dX, dw, da, ytab;
-  std::vector<double> ytab_host;  // (alive until the stream is drained)
+  DevBuf dX, dw, da;
+  ObsTable ytab;  // (alive until the stream is drained)
   // The history goes back to the host in chunks of whole time steps WHILE the loop runs (the copy
   // engine is idle otherwise and the 2.4 GB of BASELINE configs[2] take four times longer to
   // cross PCIe than to compute): an event after the last step of each chunk, a second stream for
@@ -1189,7 +1453,7 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
     (void)hipStreamSynchronize(ctx->stream);
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     for (hipEvent_t ev : chunk_done) if (ev) (void)hipEventDestroy(ev);
-    dX.release(); dw.release(); da.release(); ytab.release();
+    dX.release(); dw.release(); da.release(); ytab.dev.release();
     cusmc_dist_destroy(obs);
     return code;
   };
@@ -1220,43 +1484,14 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   if (rc) return cleanup(rc);
   // MCMC(): for t = 1..T-1: resample -> propagate -> reweight   src/mcmc.cpp:292-308
   if (T > 1) {
-    // All of Y is known here, so every step's observation vector -- the shift y_t (F = I) or the bias
-    // W y_t, rotated by Q^T when the general-F plan is (plan_affine) -- goes up in ONE table and the
-    // loop below is launches only: for a small filter the per-step uploads (two 16..2048-byte copies in
-    // the stream) would cost more than the launches.  Same values as the per-step plan, bit for bit.
     const bool fused = pf_step_is_fused(d, N);
-    if (fused) rc = pf_step_prepare(obs, G, Qw.data(), Y + d, F);
-    else rc = plan_affine(obs, Y + d, F);
+    rc = pf_obs_table(obs, fused, G, Qw.data(), Y, T, F, ytab);
     if (rc) return cleanup(rc);
-    const bool centred = obs->plan == 1;
-    const size_t row = (size_t)((d + 63) / 64) * 64;  // the matrix-core kernels stage 16*NB entries
-    ytab_host.assign((size_t)T * row, 0.0);
-    std::vector<double> b, rb;
-    for (uint32_t t = 1; t < T; ++t) {
-      const double *y = Y + (size_t)t * d;
-      double *dst = ytab_host.data() + (size_t)t * row;
-      if (centred) {
-        std::copy(y, y + d, dst);
-      } else {
-        cusmc::la::matvec(obs->W.data(), y, d, b);
-        if (!obs->plan_Qt.empty()) {
-          cusmc::la::matvec(obs->plan_Qt.data(), b.data(), d, rb);
-          b.swap(rb);
-        }
-        std::copy(b.begin(), b.end(), dst);
-      }
-    }
-    rc = ytab.reserve((size_t)T * row * 8);
-    if (rc) return cleanup(rc);
-    if (hipMemcpyAsync(ytab.p, ytab_host.data(), (size_t)T * row * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-      return cleanup(fail(CUSMC_EHIP, "observation table upload failed"));
-    const double *tab = (const double *)ytab.p;
     for (uint32_t t = 1; t < T; ++t) {
       const double *w_prev = w + (size_t)(t - 1) * N, *X_prev = X + (size_t)(t - 1) * slice;
       uint32_t *a_t = a + (size_t)t * N;
       double *X_t = X + (size_t)t * slice, *w_t = w + (size_t)t * N;
-      const double *shift_t = centred ? tab + (size_t)t * row : (const double *)obs->shift.p;
-      const double *bias_t = centred ? (const double *)obs->bias.p : tab + (size_t)t * row;
+      const double *shift_t = ytab.shift(obs, t), *bias_t = ytab.bias(obs, t);
       if (fused) {
         rc = pf_step_launch(obs, kind, df, w_prev, X_prev, N, B, scale, seed, t, 0, N, a_t, X_t, w_t,
                             CUSMC_OUT_DENSITY, shift_t, bias_t);
@@ -1333,19 +1568,51 @@ CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, 
   return done;
 }
 
+}  // namespace
+
+CUSMC_EXPORT int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T,
+                                   const double *m0, const double *C0, const double *F,
+                                   const double *G, const double *V, const double *W, float df,
+                                   const char *resampler, const char *distribution, uint32_t B,
+                                   double scale, uint64_t seed, double *X_out, double *w_out,
+                                   uint32_t *a_out)
+{
+  if (int rc = activate(ctx)) return rc;
+  // CUSMC_DEVICES="0,1,2,3": the same call shards the particles over those GPUs (SURVEY.md section 5), so
+  // that callers bound to this entry point -- the R package's run() -- use the node without a new argument;
+  // a one-entry list names the device to run on
+  std::vector<int> devs;
+  if (int rc = env_devices(devs)) return rc;
+  if (!devs.empty() && !(devs.size() == 1 && devs[0] == ctx->device))
+    return cusmc_pf_run_multi_host(devs.data(), (int)devs.size(), Y, N, d, T, m0, C0, F, G, V, W, df, resampler,
+                                   distribution, B, scale, seed, X_out, w_out, a_out);
+  return pf_run_single(ctx, Y, N, d, T, m0, C0, F, G, V, W, df, resampler, distribution, B, scale, seed, X_out, w_out,
+                       a_out);
+}
+
 // ---- the filter on several GPUs ---------------------------------------------------------------------
 //
 // MCMC()'s time loop (src/mcmc.cpp:292-308) with the particles sharded contiguously over `ndev` devices of
-// one node, one host thread and one context per device -- the exact algorithm, not an island filter, and
-// bit for bit the single-device result, because every draw is keyed by the GLOBAL particle index.  Per
-// step and device:
+// one node, one host thread and one (library-owned) context per shard -- the exact algorithm, not an island
+// filter, and bit for bit the single-device result, because every draw is keyed by the GLOBAL particle index.
+// Per step and shard:
 //     resample its own chains over the full weight vector w_{t-1}        (cusmc_metropolis_dev)
 //     fetch the rows x_{t-1}[a_i] its ancestors name from their owners   (kernels/gather.hip: peer reads)
 //     propagate and reweight its own particles                           (the single-device kernels)
-//     copy its w_t shard into every device's copy of w_t                 (hipMemcpyPeerAsync)
-// then all threads meet at a barrier.  Bytes into a device per step: 8 (N - N/R) of weights and at most
-// 8 d N/R of rows (the ancestors that live elsewhere) -- never the whole of x_{t-1}.  The reference has no
-// counterpart: its loop runs on one host (zero collective call sites).
+//     copy its w_t shard into every shard's copy of w_t                  (hipMemcpyPeerAsync)
+//     record the event "step t published"
+// Bytes into a device per step: 8 (N - N/R) of weights and at most 8 d N/R of rows (the ancestors that live
+// elsewhere) -- never the whole of x_{t-1}.  The reference has no counterpart: its loop runs on one host (zero
+// collective call sites).
+//
+// ORDERING IS ON THE DEVICES (round 3; rounds 1-2 ended every step with hipStreamSynchronize + a barrier of all
+// host threads, 20-50 us against ~10 us of compute per GPU at d = 2).  Before step t a shard's stream waits for
+// every peer's "step t-1 published" event (hipStreamWaitEvent); the host threads enqueue all T steps without
+// blocking on the GPU.  The one host-side handshake left is that an event must have been RECORDED before a peer
+// can wait for it: `published[r]` = the last step whose event shard r has recorded, read by its peers in a
+// yield loop -- which only ever waits for a peer's ENQUEUE, never for its GPU.  The double-buffered weight vector
+// needs nothing more: w_{t+1} goes into the buffer step t read, and a shard writes it at the END of its step
+// t + 1, i.e. after it has waited for every peer's step-t event.
 namespace {
 
 struct ThreadBarrier {
@@ -1373,11 +1640,24 @@ struct FilterShard {
   uint32_t first = 0, count = 0;
   cusmc_ctx *ctx = nullptr;
   cusmc_dist *obs = nullptr;
-  hipStream_t stream = nullptr;
-  DevBuf X, w, a, wfull, anc, ident;  // history [T][count][d], [T][count], [T][count]; 2 x N weights; count x d; count
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  DevBuf X, w, a, wfull, whifull, anc, ident;  // history [T][count][d], [T][count], [T][count]; 2 x N weights and their high words; count x d; count
+  ObsTable ytab;
+  std::vector<hipEvent_t> step_done;  // [t]: this shard's step t is complete and its w_t shard is on every device
+  std::atomic<uint32_t> published{0}; // last t with step_done[t] recorded (0xffffffff: gave up)
   int rc = CUSMC_OK;
   std::string error;
 };
+
+// one byte per page of [p, p + bytes): first touch of the caller's fresh output pages (see prefault_async)
+void touch_pages(void *p, size_t bytes)
+{
+  if (!p || !bytes) return;
+  volatile char *c = static_cast<volatile char *>(p);
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  for (uintptr_t g = (lo + 4095) & ~(uintptr_t)4095; g < hi; g += 4096) c[g - lo] = 0;
+  c[0] = 0;
+}
 
 }  // namespace
 
@@ -1388,8 +1668,6 @@ CUSMC_EXPORT int cusmc_pf_run_multi_host(const int *devices, int ndev, const dou
                                          double scale, uint64_t seed, double *X_out, double *w_out,
                                          uint32_t *a_out)
 {
-  if (!devices || ndev < 1) return fail(CUSMC_EINVAL, "empty device list");
-  if (ndev > cusmc::kMaxShards) return fail(CUSMC_ERANGE, "%d devices exceed the %d supported", ndev, cusmc::kMaxShards);
   if (!resampler || strcmp(resampler, "metropolis") != 0)
     return fail(CUSMC_EINVAL, "unknown resampler '%s' (known: metropolis)", resampler ? resampler : "(null)");
   int kind;
@@ -1398,26 +1676,16 @@ CUSMC_EXPORT int cusmc_pf_run_multi_host(const int *devices, int ndev, const dou
   else return fail(CUSMC_EINVAL, "unknown distribution '%s' (known: mvn, mvt)", distribution ? distribution : "(null)");
   if (!Y || !m0 || !C0 || !F || !G || !V || !W) return fail(CUSMC_EINVAL, "null model argument");
   if (N == 0 || T == 0 || d < 1) return fail(CUSMC_EINVAL, "N, T and d must be positive");
+  if (int rc = check_devices(devices, ndev)) return rc;  // (after the option strings: they are wrong on any box)
   if ((uint32_t)ndev > N) return fail(CUSMC_EINVAL, "%d devices for N = %u particles", ndev, N);
-  int visible = 0;
-  if (hipGetDeviceCount(&visible) != hipSuccess || visible == 0)
-    return fail(CUSMC_ENODEVICE, "no HIP device visible: libcusmc_hip has no CPU fallback");
-  for (int r = 0; r < ndev; ++r)
-    if (devices[r] < 0 || devices[r] >= visible)
-      return fail(CUSMC_EINVAL, "device %d out of range (%d visible)", devices[r], visible);
 
-  if (ndev == 1) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  DeviceRestore restore;
+  if (ndev == 1) {  // one device: the plain loop on that device's library-owned context
     cusmc_ctx *ctx = nullptr;
-    if (int rc = cusmc_ctx_create(devices[0], &ctx)) return rc;
-    // (no recursion through CUSMC_DEVICES: one device runs the plain loop)
-    const char *env = getenv("CUSMC_DEVICES");
-    std::string saved = env ? env : "";
-    if (env) unsetenv("CUSMC_DEVICES");
-    const int rc = cusmc_pf_run_host(ctx, Y, N, d, T, m0, C0, F, G, V, W, df, resampler, distribution, B, scale, seed,
-                                     X_out, w_out, a_out);
-    if (env) setenv("CUSMC_DEVICES", saved.c_str(), 1);
-    cusmc_ctx_destroy(ctx);
-    return rc;
+    if (int rc = pool_ctx(0, devices[0], &ctx)) return rc;
+    return pf_run_single(ctx, Y, N, d, T, m0, C0, F, G, V, W, df, resampler, distribution, B, scale, seed, X_out, w_out,
+                         a_out);
   }
 
   // peers must be able to read each other's memory (several shards may also share one device: the
@@ -1440,27 +1708,45 @@ CUSMC_EXPORT int cusmc_pf_run_multi_host(const int *devices, int ndev, const dou
   cusmc::la::eigen_sqrt(W, d, Qw.data());
 
   std::vector<FilterShard> sh(ndev);
-  {
-    const uint32_t base = N / (uint32_t)ndev, extra = N % (uint32_t)ndev;
-    uint32_t first = 0;
-    for (int r = 0; r < ndev; ++r) {
-      sh[r].device = devices[r];
-      sh[r].first = first;
-      sh[r].count = base + ((uint32_t)r < extra ? 1u : 0u);
-      first += sh[r].count;
-    }
+  for (int r = 0; r < ndev; ++r) {
+    uint64_t first, count;
+    shard_range(N, ndev, r, &first, &count);
+    sh[r].device = devices[r];
+    sh[r].first = (uint32_t)first;
+    sh[r].count = (uint32_t)count;
+    if (int rc = pool_ctx(r, devices[r], &sh[r].ctx)) return rc;
+    sh[r].stream = sh[r].ctx->stream;
   }
   ThreadBarrier barrier(ndev);
   std::atomic<bool> abort_run{false};
+  const bool trace = getenv("CUSMC_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
+  // history copy-out in chunks of whole time steps, as pf_run_single: an event after each chunk's last step
+  const size_t step_bytes_all = (size_t)N * d * 8 + (size_t)N * 12;
+  size_t chunk_bytes = 128u << 20;
+  if (const char *env = getenv("CUSMC_PF_CHUNK_BYTES")) {
+    const long long v = atoll(env);
+    if (v > 0) chunk_bytes = (size_t)v;
+  }
+  const uint32_t chunk_steps = (size_t)T * step_bytes_all <= chunk_bytes ? T : (uint32_t)std::max<size_t>(1, chunk_bytes / step_bytes_all);
+  const bool fused = cusmc::pf_step_supported(d);  // (every d <= 8: a shard's step is launch-bound long before a device's is)
+  // "step t published" must reach the other DEVICES: a system-scope release (the default).  When every shard sits
+  // on one device (the rehearsal) agent scope orders them just as well and leaves the device's L2 alone.
+  bool one_device = true;
+  for (int r = 1; r < ndev; ++r) one_device &= devices[r] == devices[0];
+  unsigned event_flags = hipEventDisableTiming;
+  if (one_device && !getenv("CUSMC_SYSTEM_FENCE")) event_flags |= hipEventDisableSystemFence;
 
-  auto worker = [&](int r) {
+  auto worker_body = [&](int r, int &passed) {
     FilterShard &me = sh[r];
     const size_t rows = me.count, slice = rows * d;
-    auto guard = [&](int rc) {  // records the first failure of this thread; the loop keeps meeting the barriers
+    auto guard = [&](int rc) {  // records the first failure of this thread and releases the peers
       if (rc && !me.rc) {
         me.rc = rc;
         me.error = g_last_error;
         abort_run.store(true);
+        me.published.store(0xffffffffu, std::memory_order_release);
       }
       return rc;
     };
@@ -1468,16 +1754,21 @@ CUSMC_EXPORT int cusmc_pf_run_multi_host(const int *devices, int ndev, const dou
       return e == hipSuccess ? CUSMC_OK : fail(CUSMC_EHIP, "%s: %s (device %d)", what, hipGetErrorString(e), me.device);
     };
     // ---- set-up
-    int rc = cusmc_ctx_create(me.device, &me.ctx);
-    if (!rc) rc = hip(hipStreamCreateWithFlags(&me.stream, hipStreamNonBlocking), "stream");
-    if (!rc) me.ctx->stream = me.stream;
+    int rc = activate(me.ctx);
+    if (!rc) rc = hip(hipStreamCreateWithFlags(&me.copy_stream, hipStreamNonBlocking), "stream");
     if (!rc) rc = cusmc_dist_create(me.ctx, kind, nullptr, V, d, df, &me.obs);
     if (!rc) rc = me.X.reserve(slice * T * 8);
     if (!rc) rc = me.w.reserve(rows * T * 8);
     if (!rc) rc = me.a.reserve(rows * T * 4);
     if (!rc) rc = me.wfull.reserve((size_t)N * 2 * 8);
+    if (!rc) rc = me.whifull.reserve((size_t)N * 2 * 4);
     if (!rc) rc = me.anc.reserve(slice * 8);
     if (!rc) rc = me.ident.reserve(rows * 4);
+    if (!rc) {
+      me.step_done.assign(T, nullptr);
+      for (uint32_t t = 0; t < T && !rc; ++t)
+        rc = hip(hipEventCreateWithFlags(&me.step_done[t], event_flags), "event");
+    }
     double *X = (double *)me.X.p, *w = (double *)me.w.p, *wfull = (double *)me.wfull.p;
     uint32_t *a = (uint32_t *)me.a.p;
     if (!rc) {
@@ -1488,75 +1779,155 @@ CUSMC_EXPORT int cusmc_pf_run_multi_host(const int *devices, int ndev, const dou
       if (!rc) rc = hip(hipMemcpyAsync(wfull, w0.data(), (size_t)N * 8, hipMemcpyHostToDevice, me.stream), "upload");
       if (!rc) rc = hip(hipMemcpyAsync(w, w0.data(), rows * 8, hipMemcpyHostToDevice, me.stream), "upload");
       if (!rc) rc = hip(hipMemsetAsync(a, 0, rows * 4, me.stream), "memset");
+      if (!rc) rc = hip(cusmc::launch_hiwords(wfull, N, (uint32_t *)me.whifull.p, me.ctx->num_cus, me.stream), "high words");
       if (!rc) rc = cusmc_initialize_dev(me.ctx, kind, df, m0, Q0.data(), d, scale, seed, me.first, me.count, X);
+      if (!rc && T > 1) rc = pf_obs_table(me.obs, fused, G, Qw.data(), Y, T, F, me.ytab);
       if (!rc) rc = hip(hipStreamSynchronize(me.stream), "initial state");
     }
     guard(rc);
-    barrier.wait();  // every shard's buffers exist and hold step 0
-    // ---- MCMC(): for t = 1..T-1: resample -> (fetch ancestors) -> propagate -> reweight
-    for (uint32_t t = 1; t < T; ++t) {
-      if (!abort_run.load()) {
-        const double *w_prev = wfull + (size_t)((t - 1) & 1) * N;
-        uint32_t *a_t = a + (size_t)t * rows;
-        double *X_t = X + (size_t)t * slice, *w_t = w + (size_t)t * rows;
-        rc = cusmc_metropolis_dev(me.ctx, w_prev, N, B, seed, t, me.first, me.count, a_t);
-        if (!rc) {
-          cusmc::ShardTable tab;
-          tab.n = ndev;
-          for (int s2 = 0; s2 < ndev; ++s2) {
-            tab.base[s2] = (const double *)sh[s2].X.p + (size_t)(t - 1) * sh[s2].count * d;
-            tab.first[s2] = sh[s2].first;
-          }
-          tab.first[ndev] = N;
-          rc = hip(cusmc::launch_gather_rows_sharded(tab, a_t, me.count, d, (double *)me.anc.p, me.ctx->num_cus, me.stream),
-                   "ancestor gather");
+    barrier.wait();  // every shard's buffers exist and hold step 0 (the only step-0 ordering: once per run)
+    passed = 1;
+    // ---- MCMC(): for t = 1..T-1: resample -> (fetch ancestors) -> propagate -> reweight, enqueued without blocking
+    for (uint32_t t = 1; t < T && !abort_run.load(std::memory_order_relaxed); ++t) {
+      rc = CUSMC_OK;
+      if (t > 1) {
+        for (int s2 = 0; s2 < ndev && !rc; ++s2) {
+          if (s2 == r) continue;
+          while (sh[s2].published.load(std::memory_order_acquire) < t - 1 && !abort_run.load(std::memory_order_relaxed))
+            std::this_thread::yield();
+          if (abort_run.load(std::memory_order_relaxed)) break;
+          rc = hip(hipStreamWaitEvent(me.stream, sh[s2].step_done[t - 1], 0), "wait for a peer's step");
         }
+        if (abort_run.load(std::memory_order_relaxed)) break;
+      }
+      // several shards on ONE device (a rehearsal, or more shards than GPUs): in rank order, not side by side -- two
+      // step kernels from two queues of one device take 110 us together where they take 2 x 32 us one after
+      // the other (N = 1e6, d = 2; profiles/r03_multi_filter.md)
+      for (int s2 = 0; s2 < r && !rc; ++s2) {
+        if (sh[s2].device != me.device) continue;
+        while (sh[s2].published.load(std::memory_order_acquire) < t && !abort_run.load(std::memory_order_relaxed))
+          std::this_thread::yield();
+        if (abort_run.load(std::memory_order_relaxed)) break;
+        rc = hip(hipStreamWaitEvent(me.stream, sh[s2].step_done[t], 0), "wait for a co-located shard");
+      }
+      if (abort_run.load(std::memory_order_relaxed)) break;
+      const double *w_prev = wfull + (size_t)((t - 1) & 1) * N;
+      uint32_t *a_t = a + (size_t)t * rows;
+      double *X_t = X + (size_t)t * slice, *w_t = w + (size_t)t * rows;
+      const double *shift_t = me.ytab.shift(me.obs, t), *bias_t = me.ytab.bias(me.obs, t);
+      cusmc::ShardStep st;
+      st.x.n = ndev;
+      for (int s2 = ndev; s2 < cusmc::kMaxShards; ++s2) {  // (pf_step_kernel's select chain runs over every entry)
+        st.x.base[s2] = nullptr;
+        st.x.first[s2] = 0xffffffffu;
+        st.w_dst[s2] = nullptr;
+        st.whi_dst[s2] = nullptr;
+      }
+      st.x.first[cusmc::kMaxShards] = 0xffffffffu;
+      for (int s2 = 0; s2 < ndev; ++s2) {
+        st.x.base[s2] = (const double *)sh[s2].X.p + (size_t)(t - 1) * sh[s2].count * d;
+        st.x.first[s2] = sh[s2].first;
+        st.w_dst[s2] = (double *)sh[s2].wfull.p + (size_t)(t & 1) * N;
+        st.whi_dst[s2] = (uint32_t *)sh[s2].whifull.p + (size_t)(t & 1) * N;
+      }
+      st.x.first[ndev] = N;
+      if (fused) {
+        // d <= 8: ONE launch per shard and step -- chain, the ancestor's row from its owner, proposal, weight, and the
+        // weight (+ its high word) stored into every shard's copy of w_t
+        if (!rc)
+          rc = pf_step_launch(me.obs, kind, df, w_prev, nullptr, N, B, scale, seed, t, me.first, me.count, a_t, X_t, w_t,
+                              CUSMC_OUT_DENSITY, shift_t, bias_t, &st, (const uint32_t *)me.whifull.p + (size_t)((t - 1) & 1) * N);
+      } else {
+        if (!rc) rc = cusmc_metropolis_dev(me.ctx, w_prev, N, B, seed, t, me.first, me.count, a_t);
+        if (!rc)
+          rc = hip(cusmc::launch_gather_rows_sharded(st.x, a_t, me.count, d, (double *)me.anc.p, me.ctx->num_cus, me.stream),
+                   "ancestor gather");
         if (!rc)
           rc = draws(me.ctx, kind, df, (const double *)me.anc.p, (const uint32_t *)me.ident.p, G, Qw.data(), nullptr, d, scale,
                      seed, t, 2u, me.first, me.count, X_t);
-        if (!rc) rc = cusmc_dist_reweight_dev(me.obs, X_t, me.count, d, Y + (size_t)t * d, F, CUSMC_OUT_DENSITY, w_t);
+        if (!rc) rc = run_logpdf(me.obs, X_t, me.count, d, CUSMC_OUT_DENSITY, w_t, shift_t, bias_t);
         for (int s2 = 0; s2 < ndev && !rc; ++s2) {
-          double *dst = (double *)sh[s2].wfull.p + (size_t)(t & 1) * N + me.first;
+          double *dst = st.w_dst[s2] + me.first;
           rc = hip(sh[s2].device == me.device
                        ? hipMemcpyAsync(dst, w_t, rows * 8, hipMemcpyDeviceToDevice, me.stream)
                        : hipMemcpyPeerAsync(dst, sh[s2].device, w_t, me.device, rows * 8, me.stream),
                    "weight exchange");
         }
-        if (!rc) rc = hip(hipStreamSynchronize(me.stream), "filter step");
-        guard(rc);
       }
-      barrier.wait();  // w_t is complete on every device, x_t on its owner
+      if (!rc) rc = hip(hipEventRecord(me.step_done[t], me.stream), "step event");
+      if (guard(rc)) break;
+      me.published.store(t, std::memory_order_release);
     }
-    // ---- this shard's columns of the history, in the reference's packing (src/run.rcpp.cpp:110-125)
+    if (trace && r == 0) fprintf(stderr, "[cusmc_pf_run_multi_host] time loop enqueued        %8.2f ms\n", (now() - t_start) * 1e3);
+    // ---- this shard's columns of the history, in the reference's packing (src/run.rcpp.cpp:110-125): chunk by
+    // chunk behind the chunk's last step on a second stream, the caller's fresh pages touched by this thread
+    // first (the GPU is still busy with the loop), one contiguous copy per step and array
     if (!abort_run.load()) {
       rc = CUSMC_OK;
-      if (X_out)
-        rc = hip(hipMemcpy2DAsync(X_out + (size_t)me.first * d, (size_t)N * d * 8, X, slice * 8, slice * 8, T,
-                                  hipMemcpyDeviceToHost, me.stream), "history copy");
-      if (!rc && w_out)
-        rc = hip(hipMemcpy2DAsync(w_out + me.first, (size_t)N * 8, w, rows * 8, rows * 8, T, hipMemcpyDeviceToHost, me.stream),
-                 "history copy");
-      if (!rc && a_out)
-        rc = hip(hipMemcpy2DAsync(a_out + me.first, (size_t)N * 4, a, rows * 4, rows * 4, T, hipMemcpyDeviceToHost, me.stream),
-                 "history copy");
-      if (!rc) rc = hip(hipStreamSynchronize(me.stream), "history copy");
+      for (uint32_t t0 = 0; t0 < T && !rc; t0 += chunk_steps) {
+        const uint32_t t1 = std::min<uint32_t>(T, t0 + chunk_steps);
+        for (uint32_t t = t0; t < t1; ++t) {
+          if (X_out) touch_pages(X_out + ((size_t)t * N + me.first) * d, slice * 8);
+          if (w_out) touch_pages(w_out + (size_t)t * N + me.first, rows * 8);
+          if (a_out) touch_pages(a_out + (size_t)t * N + me.first, rows * 4);
+        }
+        if (t1 - 1 >= 1) rc = hip(hipStreamWaitEvent(me.copy_stream, me.step_done[t1 - 1], 0), "history copy");
+        for (uint32_t t = t0; t < t1 && !rc; ++t) {
+          if (X_out)
+            rc = hip(hipMemcpyAsync(X_out + ((size_t)t * N + me.first) * d, X + (size_t)t * slice, slice * 8, hipMemcpyDeviceToHost, me.copy_stream), "history copy");
+          if (!rc && w_out)
+            rc = hip(hipMemcpyAsync(w_out + (size_t)t * N + me.first, w + (size_t)t * rows, rows * 8, hipMemcpyDeviceToHost, me.copy_stream), "history copy");
+          if (!rc && a_out)
+            rc = hip(hipMemcpyAsync(a_out + (size_t)t * N + me.first, a + (size_t)t * rows, rows * 4, hipMemcpyDeviceToHost, me.copy_stream), "history copy");
+        }
+      }
+      if (!rc) rc = hip(hipStreamSynchronize(me.copy_stream), "history copy");
       guard(rc);
     }
+    (void)hipStreamSynchronize(me.stream);
     barrier.wait();  // nobody frees a buffer a peer may still be reading
-    if (me.stream) (void)hipStreamSynchronize(me.stream);
-    me.X.release(); me.w.release(); me.a.release(); me.wfull.release(); me.anc.release(); me.ident.release();
+    passed = 2;
+    me.X.release(); me.w.release(); me.a.release(); me.wfull.release(); me.whifull.release(); me.anc.release(); me.ident.release();
+    me.ytab.dev.release();
+    for (hipEvent_t ev : me.step_done) if (ev) (void)hipEventDestroy(ev);
+    me.step_done.clear();
     if (me.obs) cusmc_dist_destroy(me.obs);
-    if (me.ctx) {
-      me.ctx->stream = nullptr;
-      cusmc_ctx_destroy(me.ctx);
-    }
-    if (me.stream) (void)hipStreamDestroy(me.stream);
+    me.obs = nullptr;
+    if (me.copy_stream) (void)hipStreamDestroy(me.copy_stream);
+    me.copy_stream = nullptr;
   };
-
+  // nothing thrown inside a shard leaves it (a bad_alloc in a std::thread would be std::terminate), and a shard
+  // that dies still meets the barriers it owes, so that its peers are not left waiting
+  std::atomic<int> go{0};  // 0: hold, 1: run, -1: a thread could not be started, nobody runs
+  auto worker = [&](int r) {
+    while (go.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+    if (go.load(std::memory_order_acquire) < 0) return;
+    int passed = 0;
+    try {
+      worker_body(r, passed);
+    } catch (...) {
+      FilterShard &me = sh[r];
+      if (!me.rc) {
+        me.rc = CUSMC_EINVAL;
+        me.error = "exception in a filter shard (out of host memory?)";
+      }
+      abort_run.store(true);
+      me.published.store(0xffffffffu, std::memory_order_release);
+      for (; passed < 2; ++passed) barrier.wait();
+    }
+  };
   std::vector<std::thread> threads;
-  for (int r = 1; r < ndev; ++r) threads.emplace_back(worker, r);
+  try {
+    for (int r = 1; r < ndev; ++r) threads.emplace_back(worker, r);
+  } catch (...) {
+    go.store(-1, std::memory_order_release);
+    for (auto &th : threads) th.join();
+    return fail(CUSMC_EINVAL, "could not start %d host threads", ndev - 1);
+  }
+  go.store(1, std::memory_order_release);
   worker(0);
   for (auto &th : threads) th.join();
+  if (trace) fprintf(stderr, "[cusmc_pf_run_multi_host] done                        %8.2f ms\n", (now() - t_start) * 1e3);
   for (int r = 0; r < ndev; ++r)
     if (sh[r].rc) {
       g_last_error = sh[r].error;

@@ -25,7 +25,14 @@
 
 namespace cusmc {
 
-template <int D, bool MVT, bool HI>
+// SH: the particle array is sharded over devices (cusmc_pf_run_multi_host; the loop of src/mcmc.cpp:292-308 with one
+// launch per shard and step): the ancestor's row is read from the shard that owns it -- straight out of a peer's
+// HBM --, and w_i and its high word are stored into EVERY shard's copy of the weight vector, so that the step
+// needs no gather kernel, no high-word pre-pass and no peer copies behind it.
+template <bool SH> struct ShardArg { typedef int type; };  // (the unsharded kernel carries no table: 4 bytes of kernarg)
+template <> struct ShardArg<true> { typedef ShardStep type; };
+
+template <int D, bool MVT, bool HI, bool SH>
 __global__ __launch_bounds__(256) void pf_step_kernel(
     float nu, const double *__restrict__ w_prev, const uint32_t *__restrict__ w_prev_hi,
     const double *__restrict__ X_prev,
@@ -33,7 +40,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
     double scale, int tri, const double *__restrict__ M, const double *__restrict__ shift,
     const double *__restrict__ bias, Epilogue ep, uint32_t k0, uint32_t k1, uint32_t step,
     uint32_t first, uint32_t count, uint32_t *__restrict__ a_out, double *__restrict__ X_out,
-    double *__restrict__ w_out)
+    double *__restrict__ w_out, typename ShardArg<SH>::type sh)
 {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
@@ -44,8 +51,24 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
     a_out[t] = anc;
     // propagate (operation order of propagate_kernel)
     double xp[D], xi[D], x[D];
+    const double *row = X_prev + (long)anc * D;
+    if constexpr (SH) {
+      // the owner of row `anc`, by a select chain over ALL kMaxShards entries (the host pads first[] with
+      // 0xffffffff): every bound and base pointer is then a kernel argument at a constant index, i.e. a scalar
+      // register -- indexed by the lane's own r they are three dependent loads per particle on top of the
+      // chain's ten
+      uint32_t f = sh.x.first[0];
+      row = sh.x.base[0];
 #pragma unroll
-    for (int k = 0; k < D; ++k) xp[k] = X_prev[(long)anc * D + k];
+      for (int s = 1; s < kMaxShards; ++s) {
+        const bool ge = anc >= sh.x.first[s];
+        row = ge ? sh.x.base[s] : row;
+        f = ge ? sh.x.first[s] : f;
+      }
+      row += (long)(anc - f) * D;
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) xp[k] = row[k];
 #pragma unroll
     for (int j = 0; j < D; j += 2) {
       double z0, z1;
@@ -91,7 +114,15 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
       const double z = z0 + z1;
       q = fma(z, z, q);
     }
-    w_out[t] = finish_generic(q, ep);
+    const double wi = finish_generic(q, ep);
+    w_out[t] = wi;
+    if constexpr (SH) {
+      const uint32_t hi = (uint32_t)(__builtin_bit_cast(uint64_t, wi) >> 32);  // (resample.hip: hiword_kernel)
+      for (int r = 0; r < sh.x.n; ++r) {
+        sh.w_dst[r][i] = wi;
+        sh.whi_dst[r][i] = hi;
+      }
+    }
   }
 }
 
@@ -103,26 +134,32 @@ hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const uint32
                           double scale, bool tri, const double *M, const double *shift,
                           const double *bias, const Epilogue &ep, uint64_t seed, uint32_t step,
                           uint32_t first, uint32_t count, uint32_t *a_out, double *X_out,
-                          double *w_out, int num_cus, hipStream_t stream)
+                          double *w_out, int num_cus, hipStream_t stream, const ShardStep *sharded)
 {
   if (count == 0) return hipSuccess;
   long blocks = ((long)count + 255) / 256;
   const long cap = (long)num_cus * 8;
   if (blocks > cap) blocks = cap;
-#define CUSMC_PF(D)                                                                                \
-  case D: {                                                                                        \
-    auto kern = kind == CUSMC_MVT ? (w_prev_hi ? pf_step_kernel<D, true, true> : pf_step_kernel<D, true, false>)   \
-                                  : (w_prev_hi ? pf_step_kernel<D, false, true> : pf_step_kernel<D, false, false>); \
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, nu, w_prev, w_prev_hi,  \
-                       X_prev, N, B, G, Q, scale, (int)tri, M, shift, bias, ep, (uint32_t)seed,    \
-                       (uint32_t)(seed >> 32), step, first, count, a_out, X_out, w_out);           \
-    break;                                                                                         \
+#define CUSMC_PFK(D, SH)                                                                                            \
+  (kind == CUSMC_MVT ? (w_prev_hi ? pf_step_kernel<D, true, true, SH> : pf_step_kernel<D, true, false, SH>)         \
+                     : (w_prev_hi ? pf_step_kernel<D, false, true, SH> : pf_step_kernel<D, false, false, SH>))
+#define CUSMC_PFL(D, SH, arg)                                                                              \
+  hipLaunchKernelGGL(CUSMC_PFK(D, SH), dim3((unsigned)blocks), dim3(256), 0, stream, nu, w_prev, w_prev_hi,    \
+                     X_prev, N, B, G, Q, scale, (int)tri, M, shift, bias, ep, (uint32_t)seed,                  \
+                     (uint32_t)(seed >> 32), step, first, count, a_out, X_out, w_out, arg)
+#define CUSMC_PF(D)                         \
+  case D: {                                 \
+    if (sharded) CUSMC_PFL(D, true, *sharded); \
+    else CUSMC_PFL(D, false, 0);            \
+    break;                                  \
   }
   switch (d) {
     CUSMC_PF(1) CUSMC_PF(2) CUSMC_PF(3) CUSMC_PF(4) CUSMC_PF(5) CUSMC_PF(6) CUSMC_PF(7) CUSMC_PF(8)
     default: return hipErrorInvalidValue;
   }
 #undef CUSMC_PF
+#undef CUSMC_PFK
+#undef CUSMC_PFL
   return hipGetLastError();
 }
 

@@ -146,23 +146,33 @@ hipError_t launch_propagate_rows(int kind, float nu, const double *X_prev, const
                                  uint32_t first, uint32_t count, double *X_out, int num_cus,
                                  hipStream_t stream);
 
-// --- kernels/pf_step.hip : resample + propagate + reweight in one launch, d <= 8 -----------------
-bool pf_step_supported(int d);
-hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const uint32_t *w_prev_hi,
-                          const double *X_prev,
-                          uint32_t N, int d, uint32_t B, const double *G, const double *Q,
-                          double scale, bool tri, const double *M, const double *shift,
-                          const double *bias, const Epilogue &ep, uint64_t seed, uint32_t step,
-                          uint32_t first, uint32_t count, uint32_t *a_out, double *X_out,
-                          double *w_out, int num_cus, hipStream_t stream);
-
-// --- kernels/gather.hip : ancestor rows of a particle array sharded over devices -----------------------
+// --- a particle array sharded contiguously over devices (cusmc_pf_run_multi_host) -------------------------------
 constexpr int kMaxShards = 16;
 struct ShardTable {
   const double *base[kMaxShards];    // shard r's rows of x_{t-1} (a pointer valid on the launching device)
   uint32_t first[kMaxShards + 1];    // shard r owns particles [first[r], first[r+1])
   int n;
 };
+// the sharded form of the fused step: rows of x_{t-1} read from their owners, w_t (and its high words, the
+// resampler's gather table of the NEXT step) written into every shard's copy of the weight vector
+struct ShardStep {
+  ShardTable x;                      // x.n == 0: not sharded
+  double *w_dst[kMaxShards];         // shard r's full-length w_t            (entry `first + t` written)
+  uint32_t *whi_dst[kMaxShards];     // shard r's full-length high words of w_t
+};
+
+// --- kernels/pf_step.hip : resample + propagate + reweight in one launch, d <= 8 -----------------
+bool pf_step_supported(int d);
+// sharded != NULL: X_prev is ignored (rows come through sharded->x) and the weights also go to sharded->w_dst / whi_dst
+hipError_t launch_pf_step(int kind, float nu, const double *w_prev, const uint32_t *w_prev_hi,
+                          const double *X_prev,
+                          uint32_t N, int d, uint32_t B, const double *G, const double *Q,
+                          double scale, bool tri, const double *M, const double *shift,
+                          const double *bias, const Epilogue &ep, uint64_t seed, uint32_t step,
+                          uint32_t first, uint32_t count, uint32_t *a_out, double *X_out,
+                          double *w_out, int num_cus, hipStream_t stream, const ShardStep *sharded = nullptr);
+
+// --- kernels/gather.hip : ancestor rows of a particle array sharded over devices -----------------------
 // out[i][:] = x[a[i]][:] for i < count, row a[i] read from the shard that owns it
 hipError_t launch_gather_rows_sharded(const ShardTable &tab, const uint32_t *a, uint32_t count, int d, double *out,
                                       int num_cus, hipStream_t stream);

@@ -123,6 +123,19 @@ int cusmc_dist_reweight_dev(cusmc_dist *dist, const double *X_dev, int64_t N, in
 int cusmc_dist_reweight_host(cusmc_dist *dist, const double *X, int64_t N, int64_t ldx,
                              const double *y, const double *F, int flags, double *out);
 
+/* The two host-pointer density calls with the ROWS sharded contiguously over `ndev` GPUs of one node: one host
+ * thread, one library-owned context and one replica of `dist` (factored and uploaded once, kept with the handle)
+ * per shard, every device fed over its own PCIe link, results written straight into `out`.  Each row's value
+ * is the single-device value bit for bit.  Fewer shards are used when N is small (about 1000 rows per shard at
+ * least); a device may be listed more than once.  cusmc_dist_pdf_host / cusmc_dist_reweight_host take this route
+ * themselves when the environment holds CUSMC_DEVICES="0,1,..." -- so the R-level MVNPDF() / MVTPDF() on a d x N
+ * matrix (src/mvn_dist.rcpp.cpp:52-58, src/mvt_dist.rcpp.cpp:60-66) use the node without a new argument.  The
+ * reference has no multi-device code. */
+int cusmc_dist_pdf_multi_host(cusmc_dist *dist, const int *devices, int ndev, const double *X, int64_t N,
+                              int64_t ldx, const double *F, int flags, double *out);
+int cusmc_dist_reweight_multi_host(cusmc_dist *dist, const int *devices, int ndev, const double *X, int64_t N,
+                                   int64_t ldx, const double *y, const double *F, int flags, double *out);
+
 /* ---- Metropolis resampler: Sampler::metropolis_hastings -- src/samplers.cpp:7-36 ----------
  * For each i in [first, first+count):  k = i; repeat B times { u ~ U[0,1); j ~ UnifInt[0,N);
  * if (u <= w[j] / w[k]) k = j; }  a[i-first] = k.      (0-based ancestors, as the reference.)
@@ -144,6 +157,15 @@ int cusmc_metropolis_log_dev(cusmc_ctx *ctx, const double *logw_dev, uint32_t N,
                              uint32_t *a_dev);
 int cusmc_metropolis_log_host(cusmc_ctx *ctx, const double *logw, uint32_t N, uint32_t B,
                               uint64_t seed, uint32_t step, uint32_t *a);
+
+/* The chains sharded contiguously over `ndev` GPUs (BASELINE configs[3]: "chains sharded over 8 x MI355X"): every
+ * device receives the whole weight vector and runs chains [first_r, first_r + count_r) into a + first_r.  The
+ * draws are keyed by the global chain index: the ancestors are the single-device ones bit for bit.
+ * log_weights != 0: w holds log-weights (cusmc_metropolis_log_*).  cusmc_metropolis_host /
+ * cusmc_metropolis_log_host take this route themselves under CUSMC_DEVICES="0,1,..." -- what the R-level
+ * metropolis_hastings() (src/samplers.rcpp.cpp:35-55) binds. */
+int cusmc_metropolis_multi_host(const int *devices, int ndev, const double *w, uint32_t N, uint32_t B,
+                                uint64_t seed, uint32_t step, int log_weights, uint32_t *a);
 
 /* ---- proposal draws ------------------------------------------------------------------------
  * propagate_K -- src/mcmc.cpp:90-160 (replaces mvn_sample_kernel_wrapper /
@@ -232,11 +254,16 @@ int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32
                       double *X_out, double *w_out, uint32_t *a_out);
 
 /* The same filter with the particles sharded over `ndev` GPUs of one node (contiguous shards, one host
- * thread + context per device, peer access over xGMI) -- the loop of src/mcmc.cpp:292-308 being sharded;
- * the reference has no multi-device code.  Exact algorithm and bit-identical results: every draw is keyed
- * by the global particle index.  Per step a device receives the other shards' weights (8 (N - N/R)
- * bytes) and only the rows x_{t-1}[a_i] its own ancestors name (at most 8 d N/R bytes).  A device may be
- * listed more than once (several shards on one GPU: how a one-GPU box rehearses this path).
+ * thread + library-owned context per shard, peer access over xGMI) -- the loop of src/mcmc.cpp:292-308 being
+ * sharded; the reference has no multi-device code.  Exact algorithm, results bit-identical to one device by
+ * construction: every draw is keyed by the global particle index.  Per step a device receives the other shards'
+ * weights (8 (N - N/R) bytes) and only the rows x_{t-1}[a_i] its own ancestors name (at most 8 d N/R bytes).
+ * The steps are ordered ON THE DEVICES (a stream waits for its peers' "step t-1 published" events); the host
+ * threads enqueue the whole loop without blocking on a GPU.  A device may be listed more than once (several
+ * shards on one GPU: how a one-GPU box rehearses this path -- and the only way it has been run so far: the
+ * branches that differ between distinct devices, hipDeviceEnablePeerAccess, hipMemcpyPeerAsync and the peer
+ * reads of kernels/gather.hip, are UNVERIFIED ON HARDWARE until a run on two physical GPUs is recorded;
+ * tests/test_gpu_parity.py::test_multi_device_run_on_two_physical_gpus does it where two are visible).
  * cusmc_pf_run_host itself takes this route when the environment holds CUSMC_DEVICES="0,1,...". */
 int cusmc_pf_run_multi_host(const int *devices, int ndev, const double *Y, uint32_t N, int d, uint32_t T,
                             const double *m0, const double *C0, const double *F, const double *G,

@@ -1048,6 +1048,122 @@ def test_cusmc_devices_environment_shards_run(cs, monkeypatch):
         cs.run(*args, seed=8)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [0, 200_000])
+def test_multi_device_run_chunked_copy_out(cs, monkeypatch, chunk):
+    """The sharded loop's own copy-out: per-step contiguous copies of each shard's columns on a second stream,
+    chunk by chunk behind the chunk's last step, one chunk and several ragged ones."""
+    N, d, T = 6007, 4, 13
+    rng = np.random.default_rng(9)
+    Y = np.cumsum(0.1 * rng.standard_normal((d, T)), axis=1)
+    I = np.eye(d)
+    args = (N, d, T, Y, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn")
+    one = cs.run(*args, seed=3, return_ancestors=True)
+    if chunk:
+        monkeypatch.setenv("CUSMC_PF_CHUNK_BYTES", str(chunk))
+    many = cs.run(*args, seed=3, return_ancestors=True, devices=[0, 0, 0])
+    for k in ("ancestors", "posterior_x", "weights"):
+        assert np.array_equal(one[k], many[k]), k
+    partial = cs.run(*args, seed=3, devices=[0, 0])
+    assert np.array_equal(partial["posterior_x"], one["posterior_x"]) and np.array_equal(partial["weights"], one["weights"])
+
+
+@pytest.mark.gpu
+def test_multi_device_run_on_two_physical_gpus(cs):
+    """the branches of cusmc_pf_run_multi_host that differ between DISTINCT devices (peer access, peer
+    copies of the weights, gather_rows_sharded_kernel reading a peer's HBM, per-thread device binding) run only
+    where two GPUs are visible -- the builder's boxes have one, the driver's node has eight."""
+    from cusmc_amd import _lib
+    if _lib.lib().cusmc_device_count() < 2:
+        pytest.skip("one GPU visible: the cross-device branches stay unverified on hardware here")
+    for N, d, T, dist, nu in ((50_003, 2, 8, "mvn", 0.0), (20_001, 64, 4, "mvt", 4.0)):
+        rng = np.random.default_rng(N)
+        Y = np.cumsum(0.1 * rng.standard_normal((d, T)), axis=1)
+        G = 0.9 * np.eye(d) + 0.05 * rng.standard_normal((d, d)) / np.sqrt(d)
+        V, W, C0 = spd(rng, d), 0.3 * spd(rng, d), spd(rng, d)
+        args = (N, d, T, Y, np.zeros(d), C0, np.eye(d), G, V, W, nu, "metropolis", dist)
+        one = cs.run(*args, seed=5, return_ancestors=True)
+        two = cs.run(*args, seed=5, return_ancestors=True, devices=[0, 1])
+        for k in ("ancestors", "posterior_x", "weights"):
+            assert np.array_equal(one[k], two[k]), (N, d, k)
+    w = np.random.default_rng(1).random(200_000)
+    assert np.array_equal(cs.Sampler.metropolis_hastings(w, B=50, seed=3), cs.Sampler.metropolis_hastings(w, B=50, seed=3, devices=[0, 1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,B,ndev", [(1_000_000, 100, 3), (5003, 40, 4), (7, 1000, 3), (100_000, 1, 2)])
+def test_multi_device_resampler_equals_one_device(cs, oracle, N, B, ndev):
+    """cusmc_metropolis_multi_host (BASELINE configs[3] from the R boundary): the chains sharded
+    over a device list below the C ABI, one host thread and library-owned context per shard, every device given
+    the whole weight vector; ancestors bitwise those of one device -- and of the oracle --, for the density and
+    the log-weight chain, ragged and tiny shards included.  Rehearsed with every shard on device 0."""
+    rng = np.random.default_rng(N + B)
+    w = np.exp(-0.5 * rng.chisquare(8, N)) * 1e-12
+    one = cs.Sampler.metropolis_hastings(w, B=B, seed=77, t=3)
+    many = cs.Sampler.metropolis_hastings(w, B=B, seed=77, t=3, devices=[0] * ndev)
+    assert np.array_equal(one, many)
+    if N <= 100_000:
+        assert np.array_equal(one, oracle.metropolis(w, B, 77, step=3))
+    lw = np.log(w)
+    assert np.array_equal(cs.Sampler.metropolis_hastings_log(lw, B=B, seed=78, t=2),
+                          cs.Sampler.metropolis_hastings_log(lw, B=B, seed=78, t=2, devices=[0] * ndev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d,dist,nu,ndev", [(100_000, 256, "mvn", 0.0, 3), (5003, 64, "mvt", 4.0, 4), (4099, 3, "mvn", 0.0, 3),
+                                              (20_011, 65, "mvn", 0.0, 2), (300, 8, "mvn", 0.0, 3)])
+def test_multi_device_density_equals_one_device(cs, N, d, dist, nu, ndev):
+    """cusmc_dist_pdf_multi_host / cusmc_dist_reweight_multi_host: the ROWS of a host batch sharded over a device
+    list, a replica of the distribution per shard; every row bitwise the one-device value (pdf(y, F) with mu != 0
+    and a dense F, reweight_G with a dense F, densities and log-densities), ragged shards, a batch too small to
+    shard, and the replicas reused by a second call."""
+    rng = np.random.default_rng(N + d)
+    sigma, mu = spd(rng, d), rng.standard_normal(d)
+    X = mu + rng.standard_normal((N, d))
+    F = np.eye(d) + 0.1 * rng.standard_normal((d, d)) / np.sqrt(d)
+    y = rng.standard_normal(d)
+    D = (cs.MultiVariateNormalDistribution(mu, sigma) if dist == "mvn" else cs.MultiVariateTStudentDistribution(mu, sigma, nu))
+    devs = [0] * ndev
+    for log in (True, False):
+        assert np.array_equal(D.pdf_batch(X, None, log=log), D.pdf_batch(X, None, log=log, devices=devs))
+        assert np.array_equal(D.pdf_batch(X, F, log=log), D.pdf_batch(X, F, log=log, devices=devs))
+        assert np.array_equal(D.reweight(X, y, F, log=log), D.reweight(X, y, F, log=log, devices=devs))
+    assert np.array_equal(D.reweight(X, y, None), D.reweight(X, y, None, devices=devs[:2]))
+    D.close()
+
+
+@pytest.mark.gpu
+def test_cusmc_devices_environment_shards_the_host_entry_points(cs, monkeypatch):
+    """CUSMC_DEVICES routes cusmc_metropolis_host, cusmc_metropolis_log_host, cusmc_dist_pdf_host and
+    cusmc_dist_reweight_host -- what rcpp/src/samplers.rcpp.cpp and rcpp/src/mv*_dist.rcpp.cpp bind -- over the
+    list; a one-entry list naming the context's own device is the plain path; the caller's current device is
+    left as it was."""
+    import torch
+    rng = np.random.default_rng(4)
+    N, d = 30_011, 32
+    sigma = spd(rng, d)
+    X = rng.standard_normal((N, d))
+    w = rng.random(N)
+    D = cs.MultiVariateNormalDistribution(None, sigma)
+    lp, a = D.pdf_batch(X), cs.Sampler.metropolis_hastings(w, B=20, seed=5)
+    al = cs.Sampler.metropolis_hastings_log(np.log(w), B=20, seed=6)
+    for env in ("0,0,0", "0"):
+        monkeypatch.setenv("CUSMC_DEVICES", env)
+        dev_before = torch.cuda.current_device()
+        assert np.array_equal(lp, D.pdf_batch(X))
+        assert np.array_equal(a, cs.Sampler.metropolis_hastings(w, B=20, seed=5))
+        assert np.array_equal(al, cs.Sampler.metropolis_hastings_log(np.log(w), B=20, seed=6))
+        assert np.array_equal(D.reweight(X, X[0], None), D.reweight(X, X[0], None, devices=[0, 0]))
+        assert torch.cuda.current_device() == dev_before
+    monkeypatch.setenv("CUSMC_DEVICES", "0,x")
+    with pytest.raises(cs.CusmcError):
+        D.pdf_batch(X)
+    with pytest.raises(cs.CusmcError):
+        cs.Sampler.metropolis_hastings(w, B=20, seed=5)
+    monkeypatch.delenv("CUSMC_DEVICES")
+    D.close()
+
+
 # --- per-particle covariances (SURVEY.md 8(f) row 4) ---------------------------------------------
 
 def _random_covariances(rng, N, d):
