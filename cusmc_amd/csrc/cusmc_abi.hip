@@ -128,6 +128,7 @@ struct cusmc_ctx {
   DevBuf scratch[6];  // host-pointer entry points: X, out, w, a, small matrices
   StagingRing ring;  // pinned staging for small parameter uploads
   DevBuf whi;        // high words of the weight vector (resampler, large N)
+  DevBuf nb4_pool;   // tail-pool counters of the assembly log-pdf kernel (kernels/logpdf_nb4_gfx950.s)
   DevBuf step_mats;  // [Q | G] of the fused filter step, re-uploaded only when they change
   std::vector<double> step_mats_host;
   // proposal-draw parameter image (packed fragments / transposed factors / diagonals + m0) of the last
@@ -288,8 +289,12 @@ int run_logpdf(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx, in
   }
   if (cusmc::mfma_supported(d, X_dev, ldx)) {
     if (int rc = ensure_frags(dist, 1)) return rc;
+    if (!ctx->nb4_pool.p) {  // the assembly kernel's tail-pool counters: zeroed once, the kernel leaves them zeroed
+      if (int rc = ctx->nb4_pool.reserve(cusmc::nb4_pool_bytes())) return rc;
+      HIP_TRY(hipMemsetAsync(ctx->nb4_pool.p, 0, cusmc::nb4_pool_bytes(), ctx->stream));
+    }
     HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan == 1, has_shift, (const double *)dist->frags.p,
-                                      shift, bias, ep, out_dev, ctx->num_cus, ctx->stream));
+                                      shift, bias, ep, out_dev, ctx->num_cus, ctx->stream, (unsigned *)ctx->nb4_pool.p));
     return CUSMC_OK;
   }
   if (!cusmc::generic_supported(d))
@@ -582,6 +587,7 @@ CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
     for (auto &b : ctx->scratch) b.release();
     ctx->draw_img.release();
     ctx->whi.release();
+    ctx->nb4_pool.release();
     ctx->step_mats.release();
     ctx->ring.release();
   } catch (...) {

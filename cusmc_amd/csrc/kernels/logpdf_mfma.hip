@@ -1,5 +1,9 @@
 // Launchers and host-side fragment packing for kernels/logpdf_mfma_kernel.h (the kernel itself
 // and the design notes live there).
+#include <atomic>
+#include <cstddef>
+#include <cstdlib>
+
 #include "logpdf_mfma_kernel.h"
 
 namespace cusmc {
@@ -55,16 +59,101 @@ static hipError_t launch_nb(const double *X, int64_t N, int64_t ldx, int d, cons
   return hipGetLastError();
 }
 
+// ---- the hand-written assembly kernel (kernels/logpdf_nb4_gfx950.s) ------------------------------------------------
+// d = 64 (NB = 4), centred, no shift, MVN log-density, 16-byte aligned rows: the headline shape (BASELINE.json: 1e6 x 64).
+// A code object of its own, embedded here as bytes and loaded once per device.
+namespace {
+const unsigned char kNb4CodeObject[] = {
+#include "logpdf_nb4_co.inc"
+};
+struct AsmKernel {
+  std::atomic<int> state{0};  // 0 not tried, 1 ready, 2 unavailable
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+};
+AsmKernel g_nb4[64];
+std::atomic_flag g_nb4_lock = ATOMIC_FLAG_INIT;
+
+hipFunction_t nb4_function()
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  AsmKernel &k = g_nb4[dev];
+  int st = k.state.load(std::memory_order_acquire);
+  if (st == 0) {
+    while (g_nb4_lock.test_and_set(std::memory_order_acquire)) {}
+    st = k.state.load(std::memory_order_acquire);
+    if (st == 0) {
+      st = 2;
+      if (hipModuleLoadData(&k.mod, kNb4CodeObject) == hipSuccess &&
+          hipModuleGetFunction(&k.fn, k.mod, "cusmc_logpdf_nb4_asm") == hipSuccess)
+        st = 1;
+      (void)hipGetLastError();
+      k.state.store(st, std::memory_order_release);
+    }
+    g_nb4_lock.clear(std::memory_order_release);
+  }
+  return st == 1 ? k.fn : nullptr;
+}
+
+// the kernel's explicit arguments, at the offsets its s_load instructions use
+struct Nb4Args {
+  const double *X;          // 0x00
+  long N;                   // 0x08
+  long ldx;                 // 0x10
+  const double *frags;      // 0x18
+  unsigned *pool;           // 0x20  tail-pool counters (kNb4PoolCounters x 128 bytes, then the done-counter)
+  unsigned rounds_dealt;    // 0x28  rounds of the round-robin deal; the tiles from rounds_dealt * G on are the pool
+  unsigned reserved;        // 0x2c
+  Epilogue ep;              // 0x30
+  double *out;              // 0x50
+  long num_tiles;           // 0x58
+  int d;                    // 0x60
+};
+static_assert(offsetof(Nb4Args, out) == 0x50 && offsetof(Nb4Args, d) == 0x60, "kernarg layout of logpdf_nb4_gfx950.s");
+}  // namespace
+
+size_t nb4_pool_bytes() { return (size_t)(kNb4PoolCounters + 1) * 128; }
+
+// true: launched.  false: not this kernel's shape (or the code object is unavailable): the caller takes the compiled one.
+static bool launch_nb4_asm(const double *X, int64_t N, int64_t ldx, const double *frags, const Epilogue &ep, double *out,
+                           int num_cus, unsigned *pool, hipStream_t stream, hipError_t *err)
+{
+  static const int mode = [] { const char *e = getenv("CUSMC_NB4_ASM"); return e ? atoi(e) : 1; }();  // 0: compiled kernel (A/B)
+  if (mode == 0 || !pool) return false;
+  const long num_tiles = (N + 15) / 16;
+  const long blocks = num_cus;
+  if (num_tiles < 64 * blocks || num_tiles >= (1L << 31)) return false;  // (a tail pool needs a body)
+  hipFunction_t fn = nb4_function();
+  if (!fn) return false;
+  static const int pool_rounds = [] { const char *e = getenv("CUSMC_NB4_POOL_ROUNDS"); return e ? atoi(e) : 16; }();
+  const long rounds = (num_tiles + blocks - 1) / blocks;
+  Nb4Args a{};
+  a.X = X; a.N = N; a.ldx = ldx; a.frags = frags; a.pool = pool;
+  a.rounds_dealt = (unsigned)(rounds - (pool_rounds < rounds - 8 ? pool_rounds : 0));
+  a.ep = ep; a.out = out; a.num_tiles = num_tiles; a.d = 64;
+  size_t size = sizeof a;
+  void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  const size_t lds_bytes = (size_t)(32 * 4 + 4 + 40 * 64) * sizeof(double);
+  *err = hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 512, 1, 1, (unsigned)lds_bytes, stream, nullptr, config);
+  return true;
+}
+
 // frags: mfma_pack_frags(., ., tri = true, .) of the lower triangular factor.  centred: z = L (x -
 // shift); otherwise z = bias + L x (the QL-rotated affine form, cusmc_abi.hip plan_affine()).
+// pool: the context's tail-pool counters for the assembly kernel (nb4_pool_bytes(), zeroed once), or NULL.
 hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool centred,
                               bool has_shift, const double *frags, const double *shift,
                               const double *bias, const Epilogue &ep, double *out, int num_cus,
-                              hipStream_t stream)
+                              hipStream_t stream, unsigned *pool)
 {
   if (N <= 0) return hipSuccess;
   const int epi = ep.out_density ? 0 : ep.kind == CUSMC_MVN ? 1 : 2;
   const bool pad = mfma_needs_pad(d, X, ldx);
+  if (d == 64 && centred && !has_shift && epi == 1 && !pad) {
+    hipError_t e = hipSuccess;
+    if (launch_nb4_asm(X, N, ldx, frags, ep, out, num_cus, pool, stream, &e)) return e;
+  }
 #define CUSMC_PADV(nb, t, s, l)                                                                   \
   (pad ? launch_nb<nb, t, s, l, true>(X, N, ldx, d, frags, shift, bias, ep, out, num_cus, stream) \
        : launch_nb<nb, t, s, l, false>(X, N, ldx, d, frags, shift, bias, ep, out, num_cus, stream))
