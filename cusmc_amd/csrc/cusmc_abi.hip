@@ -129,6 +129,7 @@ struct cusmc_ctx {
   StagingRing ring;  // pinned staging for small parameter uploads
   DevBuf whi;        // high words of the weight vector (resampler, large N)
   DevBuf nb4_pool;   // tail-pool counters of the assembly log-pdf kernel (kernels/logpdf_nb4_gfx950.s)
+  cusmc::Nb4Pool nb4_state;
   DevBuf step_mats;  // [Q | G] of the fused filter step, re-uploaded only when they change
   std::vector<double> step_mats_host;
   // proposal-draw parameter image (packed fragments / transposed factors / diagonals + m0) of the last
@@ -293,8 +294,9 @@ int run_logpdf(cusmc_dist *dist, const double *X_dev, int64_t N, int64_t ldx, in
       if (int rc = ctx->nb4_pool.reserve(cusmc::nb4_pool_bytes())) return rc;
       HIP_TRY(hipMemsetAsync(ctx->nb4_pool.p, 0, cusmc::nb4_pool_bytes(), ctx->stream));
     }
+    ctx->nb4_state.dev = (unsigned *)ctx->nb4_pool.p;
     HIP_TRY(cusmc::launch_logpdf_mfma(X_dev, N, ldx, d, dist->plan == 1, has_shift, (const double *)dist->frags.p,
-                                      shift, bias, ep, out_dev, ctx->num_cus, ctx->stream, (unsigned *)ctx->nb4_pool.p));
+                                      shift, bias, ep, out_dev, ctx->num_cus, ctx->stream, &ctx->nb4_state));
     return CUSMC_OK;
   }
   if (!cusmc::generic_supported(d))
@@ -600,7 +602,14 @@ CUSMC_EXPORT int cusmc_ctx_destroy(cusmc_ctx *ctx)
 CUSMC_EXPORT int cusmc_ctx_set_stream(cusmc_ctx *ctx, void *hip_stream)
 {
   if (!ctx) return fail(CUSMC_EINVAL, "null context");
-  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
+  if (next != ctx->stream && ctx->nb4_pool.p) {
+    // the assembly log-pdf kernel's counter blocks alternate between CONSECUTIVE launches of one stream: work still
+    // running on the old stream must be through with them before launches on the new one take their turn
+    if (int rc = activate(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  ctx->stream = next;
   return CUSMC_OK;
 }
 
@@ -608,6 +617,18 @@ CUSMC_EXPORT int cusmc_ctx_synchronize(cusmc_ctx *ctx)
 {
   if (int rc = activate(ctx)) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  // diagnostic (scripts/calib/nb4_stamps.py): CUSMC_NB4_STAMPS=<file> makes the assembly log-pdf kernel record every
+  // wave's entry / exit time behind its pool counters; a synchronize writes the last launch's records to the file
+  if (const char *path = getenv("CUSMC_NB4_STAMPS")) {
+    if (ctx->nb4_pool.p && path[0] && path[0] != '0' && path[0] != '1') {
+      std::vector<char> buf(cusmc::nb4_pool_bytes() - 8192);
+      HIP_TRY(hipMemcpy(buf.data(), (const char *)ctx->nb4_pool.p + 8192, buf.size(), hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(path, "wb")) {
+        fwrite(buf.data(), 1, buf.size(), f);
+        fclose(f);
+      }
+    }
+  }
   return CUSMC_OK;
 }
 

@@ -102,10 +102,13 @@ struct Nb4Args {
   long N;                   // 0x08
   long ldx;                 // 0x10
   const double *frags;      // 0x18
-  unsigned *pool;           // 0x20  tail-pool counters (kNb4PoolCounters x 128 bytes, then the done-counter)
+  unsigned *pool;           // 0x20  this launch's tail-pool counters (kNb4PoolCounters x 128 bytes, zero)
   unsigned rounds_dealt;    // 0x28  rounds of the round-robin deal; the tiles from rounds_dealt * G on are the pool
-  unsigned reserved;        // 0x2c
-  Epilogue ep;              // 0x30
+  unsigned stamps;          // 0x2c  diagnostic: 1, 2 = record per-wave (entry, exit) s_memrealtime pairs in area 0, 1
+  double lognorm;           // 0x30
+  unsigned *pool_other;     // 0x38  the other launch parity's counters: zeroed by this launch for the next one
+  char *stamp_records;      // 0x40
+  long unused;              // 0x48
   double *out;              // 0x50
   long num_tiles;           // 0x58
   int d;                    // 0x60
@@ -113,25 +116,34 @@ struct Nb4Args {
 static_assert(offsetof(Nb4Args, out) == 0x50 && offsetof(Nb4Args, d) == 0x60, "kernarg layout of logpdf_nb4_gfx950.s");
 }  // namespace
 
-size_t nb4_pool_bytes() { return (size_t)(kNb4PoolCounters + 1) * 128; }
+size_t nb4_pool_bytes() { return 8192 + 2 * 32768; }  // two counter blocks of 32 x 128 bytes | 8192: two stamp areas of 256 workgroups x 8 waves x 16 bytes
 
 // true: launched.  false: not this kernel's shape (or the code object is unavailable): the caller takes the compiled one.
 static bool launch_nb4_asm(const double *X, int64_t N, int64_t ldx, const double *frags, const Epilogue &ep, double *out,
-                           int num_cus, unsigned *pool, hipStream_t stream, hipError_t *err)
+                           int num_cus, Nb4Pool *pool, hipStream_t stream, hipError_t *err)
 {
   static const int mode = [] { const char *e = getenv("CUSMC_NB4_ASM"); return e ? atoi(e) : 1; }();  // 0: compiled kernel (A/B)
-  if (mode == 0 || !pool) return false;
+  if (mode == 0 || !pool || !pool->dev) return false;
   const long num_tiles = (N + 15) / 16;
   const long blocks = num_cus;
-  if (num_tiles < 64 * blocks || num_tiles >= (1L << 31)) return false;  // (a tail pool needs a body)
+  if (blocks < 4 || num_tiles < 64 * blocks || num_tiles >= (1L << 31)) return false;  // (a tail pool needs a body, and every one of the 32 counters a wave: 8 b + w covers them from 4 workgroups up)
   hipFunction_t fn = nb4_function();
   if (!fn) return false;
-  static const int pool_rounds = [] { const char *e = getenv("CUSMC_NB4_POOL_ROUNDS"); return e ? atoi(e) : 16; }();
+  static const int pool_rounds = [] { const char *e = getenv("CUSMC_NB4_POOL_ROUNDS"); return e ? atoi(e) : 48; }();
   const long rounds = (num_tiles + blocks - 1) / blocks;
   Nb4Args a{};
-  a.X = X; a.N = N; a.ldx = ldx; a.frags = frags; a.pool = pool;
+  // two counter blocks, alternating from launch to launch on this stream (the kernel zeroes the one it does not use)
+  const unsigned parity = pool->launches++ & 1u;
+  char *base = reinterpret_cast<char *>(pool->dev);
+  a.X = X; a.N = N; a.ldx = ldx; a.frags = frags;
+  a.pool = reinterpret_cast<unsigned *>(base + parity * 4096);
+  a.pool_other = reinterpret_cast<unsigned *>(base + (parity ^ 1u) * 4096);
+  a.stamp_records = base + 8192;
   a.rounds_dealt = (unsigned)(rounds - (pool_rounds < rounds - 8 ? pool_rounds : 0));
-  a.ep = ep; a.out = out; a.num_tiles = num_tiles; a.d = 64;
+  static const bool stamps = [] { const char *e = getenv("CUSMC_NB4_STAMPS"); return e && e[0] && e[0] != '0'; }();
+  static std::atomic<unsigned> launches{0};
+  a.stamps = stamps && blocks <= 256 ? 1u + (launches.fetch_add(1) & 1u) : 0u;
+  a.lognorm = ep.lognorm; a.out = out; a.num_tiles = num_tiles; a.d = 64;
   size_t size = sizeof a;
   void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   const size_t lds_bytes = (size_t)(32 * 4 + 4 + 40 * 64) * sizeof(double);
@@ -141,11 +153,12 @@ static bool launch_nb4_asm(const double *X, int64_t N, int64_t ldx, const double
 
 // frags: mfma_pack_frags(., ., tri = true, .) of the lower triangular factor.  centred: z = L (x -
 // shift); otherwise z = bias + L x (the QL-rotated affine form, cusmc_abi.hip plan_affine()).
-// pool: the context's tail-pool counters for the assembly kernel (nb4_pool_bytes(), zeroed once), or NULL.
+// pool: the stream's tail-pool counters for the assembly kernel (nb4_pool_bytes() of device memory, zeroed once) and
+// its launch count, or NULL.
 hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool centred,
                               bool has_shift, const double *frags, const double *shift,
                               const double *bias, const Epilogue &ep, double *out, int num_cus,
-                              hipStream_t stream, unsigned *pool)
+                              hipStream_t stream, Nb4Pool *pool)
 {
   if (N <= 0) return hipSuccess;
   const int epi = ep.out_density ? 0 : ep.kind == CUSMC_MVN ? 1 : 2;

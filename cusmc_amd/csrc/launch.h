@@ -72,14 +72,19 @@ bool mfma_supported(int d, const void *X, int64_t ldx);
 void mfma_pack_frags(const double *M, int d, bool tri, double *frags);
 // frags: the LOWER TRIANGULAR factor packed with tri = true.  centred: shift, no bias; !centred:
 // bias, no shift.  has_shift = false promises the shift vector is all zeros.
-// pool: tail-pool counters for the assembly kernel of the d = 64 headline shape (nb4_pool_bytes() of device memory,
-// zeroed once, one block per stream), or NULL: the compiled kernel
+// pool: tail-pool state for the assembly kernel of the d = 64 headline shape (kernels/logpdf_nb4_gfx950.s), ONE PER
+// STREAM: nb4_pool_bytes() of device memory, zeroed once, and the number of launches that used it (consecutive
+// launches alternate between its two counter blocks); NULL: the compiled kernel
 constexpr int kNb4PoolCounters = 32;
+struct Nb4Pool {
+  unsigned *dev = nullptr;
+  unsigned launches = 0;
+};
 size_t nb4_pool_bytes();
 hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bool centred,
                               bool has_shift, const double *frags, const double *shift,
                               const double *bias, const Epilogue &ep, double *out, int num_cus,
-                              hipStream_t stream, unsigned *pool = nullptr);
+                              hipStream_t stream, Nb4Pool *pool = nullptr);
 
 // --- kernels/logpdf_mfma_wide.hip : 128 < d <= 256, output blocks split over the waves -----------
 bool mfma_wide_supported(int d, const void *X, int64_t ldx);
