@@ -40,7 +40,7 @@ D = 64
 ALGO_BYTES_PER_EVAL = 8 * D + 8  # read the particle once, write one log-density
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MH_N, MH_B, MH_D = 100_000, 1000, 32
-EXPECTED_KERNEL = "cusmc::logpdf_mfma_kernel<4, true, false, 0, 1, false>"
+EXPECTED_KERNEL = "cusmc_logpdf_nb4_asm"  # kernels/logpdf_nb4_gfx950.s (CUSMC_NB4_ASM=0: cusmc::logpdf_mfma_kernel<4, true, false, 0, 1, false>)
 C5_N, C5_D = 4_000_000, 256      # BASELINE configs[4]: d=256 MVN, 4e6 particles over the node
 F64_MFMA_PEAK_TFLOPS = 78.6      # public spec; measured 77.7 (profiles/r01_calibration.txt)
 PF_N = 1_000_000                 # BASELINE configs[2]: particle filter, 1e6 particles
@@ -70,7 +70,7 @@ def pmc_child(n, d, launches):
     D_.close()
 
 
-def collect_hbm_traffic(n, d, kernel_substr="logpdf_mfma"):
+def collect_hbm_traffic(n, d, kernel_substr=("logpdf_nb4", "logpdf_mfma")):
     """HBM bytes per launch of the dominant kernel from the PMC counters, collected as
     MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
     (4 TCC slots; 3 + 2 do not fit), counter unit KiB, and the gfx950 correction: FETCH_SIZE
@@ -94,7 +94,7 @@ def collect_hbm_traffic(n, d, kernel_substr="logpdf_mfma"):
                 for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                     with open(path) as f:
                         for row in csv.DictReader(f):
-                            if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                            if any(k in row.get("Kernel_Name", "") for k in kernel_substr) and row.get("Counter_Name") == counter:
                                 vals.append(float(row["Counter_Value"]))
                                 names.add(row["Kernel_Name"])
                 if not vals:
@@ -243,6 +243,8 @@ def main():
     for _ in range(args.steps):
         mvn.pdf_dev(X, out)
     ev1.record()
+    while not ev1.query():  # busy-poll: a blocking synchronize wakes tens of microseconds late, which K = 20 steps of
+        pass                # ~90 us would carry as 3 %; the barrier + synchronize below then return at once
     barrier()
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
@@ -282,7 +284,11 @@ def main():
             "config": {"workload": "mvn_logpdf fp64: N=%d particles per GPU x d=%d, Sigma = AA^T/d + I "
                                    "(seed 1), device-resident, one launch per step" % (N_PER_GPU, D),
                        "particles_per_gpu": N_PER_GPU, "d": D, "parallelism": "particle-sharded x%d, "
-                       "no data-path collective" % world},
+                       "no data-path collective" % world,
+                       # the clock governor's transient: --warmup below 600 is topped up to 600 untimed launches
+                       "untimed_launches_before_the_timed_region": settle + args.warmup,
+                       "kernel_source": "hand-written assembly (kernels/logpdf_nb4_gfx950.s)"
+                       if os.environ.get("CUSMC_NB4_ASM", "1") != "0" else "compiled HIP (CUSMC_NB4_ASM=0)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic["hbm_bytes"],
@@ -322,7 +328,7 @@ def main():
         def _late():
             line["aux_error"] = "auxiliary legs did not finish within %d s: headline reported without them" % AUX_TIMEOUT_S
             emit()
-            os._exit(0)
+            os._exit(3)  # (non-zero: the launcher tears the peers down and the driver sees the failure)
         watchdog = threading.Timer(AUX_TIMEOUT_S, _late)
         watchdog.daemon = True
         watchdog.start()
@@ -336,7 +342,7 @@ def main():
                 line["aux_error"] = "leg '%s' failed; later legs not run" % name
                 emit()
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(3)  # (the headline line is out; the exit code says a leg failed and takes the peers down with it)
         return {"error": repr(exc)}
 
     def timed_max(fn, reps, warm=3):

@@ -313,47 +313,70 @@ static __device__ __forceinline__ void chi_square_clayout(const ChiSquare &cs, u
 // One Metropolis chain (Sampler::metropolis_hastings, src/samplers.cpp:21-35):
 //     k = i;  B times { u ~ U[0,1); j ~ UnifInt[0,N); if (u <= w[j] / w[k]) k = j; }
 // The draw order (u, then j), the division and the `<=` are the reference's, so a NaN ratio never
-// accepts.  The random numbers and the gather of step n do not depend on the chain state, only
-// the compare does, so the loop is unrolled by four: four Philox blocks and four gathers are in
+// accepts.  Draws: RNG contract 3 (philox.h) -- ONE Philox block per TWO steps (the ten rounds were ~50 of the
+// ~75 VALU instructions of a step).  The random numbers and the gather of step n do not depend on the chain
+// state, only the compare does, so the loop is unrolled by four: two Philox blocks and four gathers are in
 // flight before the four dependent accept tests.  The chain state is updated by SELECTS, not inside
 // `if (accept) { k = j; ... }`: with an accept condition of the form `a || expensive(b)` hipcc 7.2
 // (gfx950) dropped the `k = j` of the second disjunct -- the register that held j was reused for
 // expensive()'s result and `k` got its old value back while its companion (the weight) was updated --
 // caught by the bit-exact comparison with the oracle, twice.
+struct MhDraw4 {
+  uint32_t a[4], j[4];
+};
+// the draws of steps n .. n+3 (n a multiple of 4) of chain i
+static __device__ __forceinline__ MhDraw4 mh_draw4(uint32_t i, uint32_t n, uint32_t step, uint32_t N, uint32_t tN,
+                                                   uint32_t k0, uint32_t k1)
+{
+  MhDraw4 d;
+  const u32x4 r0 = philox4x32_10(i, n >> 1, step, 1u, k0, k1), r1 = philox4x32_10(i, (n >> 1) + 1u, step, 1u, k0, k1);
+  d.a[0] = r0.x, d.a[1] = r0.z, d.a[2] = r1.x, d.a[3] = r1.z;
+  d.j[0] = mh_index(r0.y, i, n, step, N, tN, k0, k1);
+  d.j[1] = mh_index(r0.w, i, n + 1u, step, N, tN, k0, k1);
+  d.j[2] = mh_index(r1.y, i, n + 2u, step, N, tN, k0, k1);
+  d.j[3] = mh_index(r1.w, i, n + 3u, step, N, tN, k0, k1);
+  return d;
+}
+// one step's draws (the loop's remainder)
+static __device__ __forceinline__ void mh_draw1(uint32_t i, uint32_t n, uint32_t step, uint32_t N, uint32_t tN, uint32_t k0,
+                                                uint32_t k1, uint32_t &a, uint32_t &j)
+{
+  const u32x4 r = philox4x32_10(i, n >> 1, step, 1u, k0, k1);
+  a = (n & 1u) ? r.z : r.x;
+  j = mh_index((n & 1u) ? r.w : r.y, i, n, step, N, tN, k0, k1);
+}
+
 static __device__ __forceinline__ uint32_t metropolis_chain(const double *__restrict__ w, uint32_t N,
                                                             uint32_t B, uint32_t i, uint32_t step,
                                                             uint32_t k0, uint32_t k1)
 {
+  const uint32_t tN = mh_tn(N);
   uint32_t k = i;
   double wk = w[i];
   uint32_t n = 0;
   for (; n + 4 <= B; n += 4) {
-    double u[4], wj[4];
-    uint32_t j[4];
+    const MhDraw4 d = mh_draw4(i, n, step, N, tN, k0, k1);
+    double wj[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const u32x4 r = philox4x32_10(i, n + c, step, 1u, k0, k1);
-      u[c] = u01_53(r.x, r.y);
-      j[c] = uint_below(r.z, r.w, N);
 #ifdef CUSMC_ABL_MH_COALESCED  // ablation builds only (scripts/calib/mh_time.py): the chain without its random gather
-      wj[c] = w[(i + n + c) % N] + (double)(j[c] & 1);
+      wj[c] = w[(i + n + c) % N] + (double)(d.j[c] & 1);
 #else
-      wj[c] = w[j[c]];
+      wj[c] = w[d.j[c]];
 #endif
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const bool acc = u[c] <= wj[c] / wk;
-      k = acc ? j[c] : k;
+      const bool acc = mh_accept(d.a[c], wj[c] / wk, i, n + c, step, k0, k1);
+      k = acc ? d.j[c] : k;
       wk = acc ? wj[c] : wk;
     }
   }
   for (; n < B; ++n) {
-    const u32x4 r = philox4x32_10(i, n, step, 1u, k0, k1);
-    const double u = u01_53(r.x, r.y);
-    const uint32_t j = uint_below(r.z, r.w, N);
+    uint32_t a, j;
+    mh_draw1(i, n, step, N, tN, k0, k1, a, j);
     const double wj = w[j];
-    const bool acc = u <= wj / wk;
+    const bool acc = mh_accept(a, wj / wk, i, n, step, k0, k1);
     k = acc ? j : k;
     wk = acc ? wj : wk;
   }
@@ -364,14 +387,15 @@ static __device__ __forceinline__ uint32_t metropolis_chain(const double *__rest
 // w[j] (sign, exponent, 20 mantissa bits: a lower bound of w[j] within 2^-20).  At N = 1e6 the
 // doubles are 8 MB -- twice one XCD's 4 MB L2 -- and the chain is bound by L2 misses (85 us for
 // B = 10); the 4 MB table fits and the same gathers take 45 us (scripts/calib/gather_probe.hip).
-// The truncated values decide every step whose outcome they CAN decide:
-//     wj in [a, a(1+2^-20)), wk in [b, b(1+2^-20))   =>   wj/wk in ( (a/b)(1-2^-19), (a/b)(1+2^-19) )
-//     u b <= a (1 - 2^-18)  =>  u <= fl(wj / wk): accept;    u b > a (1 + 2^-18)  =>  reject
+// The truncated values decide every step whose outcome they CAN decide.  With u in [lo, hi) (its 32 leading
+// bits: philox.h), wj in [a, a(1+2^-20)), wk in [b, b(1+2^-20)):
+//     wj/wk in ( (a/b)(1-2^-19), (a/b)(1+2^-19) )
+//     hi b <= a (1 - 2^-18)  =>  hi <= fl(wj / wk): the reference's test accepts;    lo b > a (1 + 2^-18)  =>  rejects
 // (margins 2x wider than needed cover every rounding in sight), and only the sliver in between --
 // about 2^-17 of the steps -- or operands outside the comfortable range (zero, denormal, tiny, huge,
-// negative, NaN) fetch the two doubles and run the reference's own test, u <= w[j] / w[k].  The
-// index sequence is therefore IDENTICAL to metropolis_chain's, and the common step saves the fp64
-// division as well.
+// negative, NaN) fetch the two doubles and run the reference's own test, u <= w[j] / w[k] (mh_accept).  The
+// index sequence is therefore IDENTICAL to metropolis_chain's, and the common step also saves the fp64
+// division.
 static __device__ __forceinline__ double hi_to_double(uint32_t hi)
 {
   return __builtin_bit_cast(double, (uint64_t)hi << 32);
@@ -381,22 +405,24 @@ static __device__ __forceinline__ double hi_to_double(uint32_t hi)
 static __device__ __forceinline__ bool hi_comfortable(uint32_t hi) { return ((hi >> 20) - 123u) <= 1800u; }
 
 // One step of the chain on the truncated table: (k, bh) = current index and the high word of its
-// weight; returns with them updated.
-static __device__ __forceinline__ void metropolis_step_hi(const double *__restrict__ w, double u, uint32_t j,
-                                                          uint32_t ah, uint32_t &k, uint32_t &bh)
+// weight; returns with them updated.  ua = the 32 leading bits of u.
+static __device__ __forceinline__ void metropolis_step_hi(const double *__restrict__ w, uint32_t ua, uint32_t j,
+                                                          uint32_t ah, uint32_t &k, uint32_t &bh, uint32_t i, uint32_t n,
+                                                          uint32_t step, uint32_t k0, uint32_t k1)
 {
   bool acc, decided = false;
   if (hi_comfortable(ah) && hi_comfortable(bh)) {
-    const double a = hi_to_double(ah), p = u * hi_to_double(bh);
-    if (p <= a * (1.0 - 0x1p-18)) {
+    const double lo = (double)ua * 0x1.0p-32, hi = lo + 0x1.0p-32;
+    const double a = hi_to_double(ah), b = hi_to_double(bh);
+    if (hi * b <= a * (1.0 - 0x1p-18)) {
       acc = true;
       decided = true;
-    } else if (p > a * (1.0 + 0x1p-18)) {
+    } else if (lo * b > a * (1.0 + 0x1p-18)) {
       acc = false;
       decided = true;
     }
   }
-  if (!decided) acc = u <= w[j] / w[k];  // the reference's own test, on the full doubles
+  if (!decided) acc = mh_accept(ua, w[j] / w[k], i, n, step, k0, k1);  // the reference's own test, on the full doubles
   k = acc ? j : k;
   bh = acc ? ah : bh;
 }
@@ -406,25 +432,21 @@ static __device__ __forceinline__ uint32_t metropolis_chain_hi(const double *__r
                                                                uint32_t B, uint32_t i, uint32_t step,
                                                                uint32_t k0, uint32_t k1)
 {
+  const uint32_t tN = mh_tn(N);
   uint32_t k = i, bh = whi[i];
   uint32_t n = 0;
   for (; n + 4 <= B; n += 4) {
-    double u[4];
-    uint32_t j[4], ah[4];
+    const MhDraw4 d = mh_draw4(i, n, step, N, tN, k0, k1);
+    uint32_t ah[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const u32x4 r = philox4x32_10(i, n + c, step, 1u, k0, k1);
-      u[c] = u01_53(r.x, r.y);
-      j[c] = uint_below(r.z, r.w, N);
-      ah[c] = whi[j[c]];
-    }
+    for (int c = 0; c < 4; ++c) ah[c] = whi[d.j[c]];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) metropolis_step_hi(w, u[c], j[c], ah[c], k, bh);
+    for (int c = 0; c < 4; ++c) metropolis_step_hi(w, d.a[c], d.j[c], ah[c], k, bh, i, n + c, step, k0, k1);
   }
   for (; n < B; ++n) {
-    const u32x4 r = philox4x32_10(i, n, step, 1u, k0, k1);
-    const uint32_t j = uint_below(r.z, r.w, N);
-    metropolis_step_hi(w, u01_53(r.x, r.y), j, whi[j], k, bh);
+    uint32_t a, j;
+    mh_draw1(i, n, step, N, tN, k0, k1, a, j);
+    metropolis_step_hi(w, a, j, whi[j], k, bh, i, n, step, k0, k1);
   }
   return k;
 }
@@ -462,33 +484,28 @@ static __device__ __forceinline__ uint32_t metropolis_chain_log(const double *__
                                                                 uint32_t B, uint32_t i, uint32_t step,
                                                                 uint32_t k0, uint32_t k1)
 {
+  const uint32_t tN = mh_tn(N);
   uint32_t k = i;
   double lk = lw[i];
   uint32_t n = 0;
   for (; n + 4 <= B; n += 4) {
-    double u[4], lj[4];
-    uint32_t j[4];
+    const MhDraw4 d = mh_draw4(i, n, step, N, tN, k0, k1);
+    double lj[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const u32x4 r = philox4x32_10(i, n + c, step, 1u, k0, k1);
-      u[c] = u01_53(r.x, r.y);
-      j[c] = uint_below(r.z, r.w, N);
-      lj[c] = lw[j[c]];
-    }
+    for (int c = 0; c < 4; ++c) lj[c] = lw[d.j[c]];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const double t = lj[c] - lk;
-      const bool acc = (t >= 0.0) | (u[c] <= exp_nonpos(t));
-      k = acc ? j[c] : k;  // (selects, not branches: see the note on metropolis_chain)
+      const bool acc = (t >= 0.0) | mh_accept(d.a[c], exp_nonpos(t), i, n + c, step, k0, k1);
+      k = acc ? d.j[c] : k;  // (selects, not branches: see the note on metropolis_chain)
       lk = acc ? lj[c] : lk;
     }
   }
   for (; n < B; ++n) {
-    const u32x4 r = philox4x32_10(i, n, step, 1u, k0, k1);
-    const double u = u01_53(r.x, r.y);
-    const uint32_t j = uint_below(r.z, r.w, N);
+    uint32_t a, j;
+    mh_draw1(i, n, step, N, tN, k0, k1, a, j);
     const double lj = lw[j], t = lj - lk;
-    const bool acc = (t >= 0.0) | (u <= exp_nonpos(t));
+    const bool acc = (t >= 0.0) | mh_accept(a, exp_nonpos(t), i, n, step, k0, k1);
     k = acc ? j : k;
     lk = acc ? lj : lk;
   }

@@ -8,7 +8,9 @@
 //
 //   key     = (seed_lo, seed_hi)
 //   counter = (index, sub, step, domain)
-//   domain  : 1 resampler          sub = iteration n          words 0,1 -> u; 2,3 -> j
+//   domain  : 1 resampler          sub = iteration n / 2      half n % 2: word 2h -> leading bits of u, 2h+1 -> j
+//             7 resampler: the next 53 bits of u (sub = n), when the first 32 cannot decide
+//             16+q resampler: index redraws (sub = n), Lemire's rejection
 //             2 proposal normals   sub = component pair j/2   Box-Muller on (0,1],(0,1)
 //             3 chi-square normals sub = j*64 + attempt
 //             4 initial normals    sub = component pair
@@ -50,12 +52,46 @@ __host__ __device__ __forceinline__ double u01_53(uint32_t hi, uint32_t lo)
   return (double)(v >> 11) * 0x1.0p-53;
 }
 
-// floor(v * N / 2^64), v the 64-bit word (hi,lo): uniform on [0,N) to within N * 2^-64.
-__host__ __device__ __forceinline__ uint32_t uint_below(uint32_t hi, uint32_t lo, uint32_t N)
+// ---- resampler draws, RNG contract 3 (restated in oracle/cusmc_oracle.c: mh_index, mh_accept) ----------------------
+// One block (i, n / 2, step, 1) serves chain steps n and n + 1: half h = n % 2 gives a = word 2h (the leading 32 bits
+// of u) and b = word 2h + 1 (the index candidate).  Both draws stay exact: more bits are read only when these cannot
+// decide (probability 2^-32 and < N 2^-32 per step).
+
+// tN = (2^32 - N) mod N: candidates whose low product word is below it are redrawn (Lemire's unbiased bounded integer)
+__host__ __device__ __forceinline__ uint32_t mh_tn(uint32_t N) { return (0u - N) % N; }
+
+// j uniform on [0, N) from the candidate b; redraws come from blocks (i, n, step, 16 + q), words 0..3 in order
+__host__ __device__ __forceinline__ uint32_t mh_index(uint32_t b, uint32_t i, uint32_t n, uint32_t step, uint32_t N,
+                                                      uint32_t tN, uint32_t k0, uint32_t k1)
 {
-  // (hi*2^32 + lo) * N >> 64  ==  (hi*N + ((lo*N) >> 32)) >> 32
-  const uint64_t t = (uint64_t)hi * N + (((uint64_t)lo * N) >> 32);
-  return (uint32_t)(t >> 32);
+  uint64_t m = (uint64_t)b * N;
+  if ((uint32_t)m < tN) {
+    for (uint32_t q = 0;; ++q) {
+      const u32x4 r = philox4x32_10(i, n, step, 16u + q, k0, k1);
+      m = (uint64_t)r.x * N;
+      if ((uint32_t)m >= tN) break;
+      m = (uint64_t)r.y * N;
+      if ((uint32_t)m >= tN) break;
+      m = (uint64_t)r.z * N;
+      if ((uint32_t)m >= tN) break;
+      m = (uint64_t)r.w * N;
+      if ((uint32_t)m >= tN) break;
+    }
+  }
+  return (uint32_t)(m >> 32);
+}
+
+// the reference's test u <= r (src/samplers.cpp:29) for the uniform real u whose leading 32 bits are a
+__host__ __device__ __forceinline__ bool mh_accept(uint32_t a, double r, uint32_t i, uint32_t n, uint32_t step,
+                                                   uint32_t k0, uint32_t k1)
+{
+  const double lo = (double)a * 0x1.0p-32, hi = lo + 0x1.0p-32;  // both exact
+  bool acc = hi <= r;                                             // (false for a NaN ratio: never accepts)
+  if (!acc && lo <= r) {                                          // r inside u's cell: the next 53 bits decide
+    const u32x4 x = philox4x32_10(i, n, step, 7u, k0, k1);
+    acc = u01_53(x.x, x.y) <= r * 0x1.0p32 - (double)a;           // r 2^32 in [a, a + 1]: the difference is exact
+  }
+  return acc;
 }
 
 }  // namespace cusmc

@@ -66,7 +66,9 @@ const char *cusmc_version(void);
 /* Version of the counter-based RNG contract the draws follow: which Philox block and
  * which words of it feed which draw.  A seed reproduces a result only under the same contract version.
  * 2 (round 3): chi-square draws keyed by the component pair -- closed form for nu = 2, 4, pair-shared
- * Marsaglia-Tsang attempts otherwise; everything else as contract 1.  (The reference has no contract: it
+ * Marsaglia-Tsang attempts otherwise.  3 (round 3): the resampler takes ONE Philox block per TWO chain steps (32
+ * leading bits of u and a 32-bit index candidate per step, both completed exactly from further blocks in the rare
+ * cases where they cannot decide); everything else as contract 1.  (The reference has no contract: it
  * reseeds from std::random_device per call, src/statistics.cc.cpp:231-232, 360-361.) */
 int cusmc_rng_contract(void);
 const char *cusmc_last_error(void);

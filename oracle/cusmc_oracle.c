@@ -343,7 +343,7 @@ ORACLE_API int oracle_logpdf_hoisted(const double *X, long N, long ldx, const do
  *   counter = (index, sub, step, domain)
  * domain tags: 1 resampler, 2 proposal normals, 3 chi-square normals, 4 initial normals,
  *              5 chi-square accept/boost uniforms, 6 chi-square closed-form uniforms (contract 2: see
- *              chi_square_for).
+ *              chi_square_for), 7 resampler accept refinement, 16 + q resampler index redraws (contract 3).
  * ---------------------------------------------------------------------------------------- */
 #define PHILOX_M0 0xD2511F53u
 #define PHILOX_M1 0xCD9E8D57u
@@ -384,25 +384,75 @@ static inline uint32_t uint_below(uint32_t hi, uint32_t lo, uint32_t N)
  * order); accept iff (u <= w[j] / w[k]) -- the same division and <=, so a NaN ratio never
  * accepts (man/metropolis_hastings.Rd:22-27).  u, j, k are thread-private here (the
  * reference's shared declarations are a data race).
- * One Philox block per (i, n): words 0,1 -> u; words 2,3 -> j.
- * `step` plays the role of the reference's t (a_t[t*N+i] = k); the caller owns the offset. */
+ * `step` plays the role of the reference's t (a_t[t*N+i] = k); the caller owns the offset.
+ *
+ * RNG CONTRACT 3 (round 3; contracts 1-2 spent one Philox block per chain step: 53 bits for u, 64 for j).  ONE block
+ * serves TWO steps, and both draws stay EXACT by taking more bits only when the first 32 cannot decide:
+ *   block (i, n / 2, step, 1), half h = n % 2:  a = word 2h,  b = word 2h + 1.
+ *   u  is a uniform real on [0, 1) whose leading 32 bits are a:  u in [a 2^-32, (a + 1) 2^-32).  With
+ *      r = w[j] / w[k] (the reference's division):  (a + 1) 2^-32 <= r  accepts,  a 2^-32 > r  rejects, and only when r
+ *      lies inside u's cell (probability 2^-32 per step) are the next 53 bits read: V = u01_53 of words 0, 1 of block
+ *      (i, n, step, 7), accept iff V <= r 2^32 - a (exact: the cell's offset).  A NaN ratio rejects.  This IS the
+ *      reference's test u <= w[j] / w[k], with an 85-bit u instead of a 53-bit one.
+ *   j  is uniform on {0 .. N-1} WITHOUT bias (Lemire's multiply-and-reject): m = b N, j = m >> 32, unless the low word
+ *      of m is below tN = (2^32 - N) mod N (probability < N 2^-32): then b is redrawn -- words 0, 1, 2, 3 of block
+ *      (i, n, step, 16), then of (i, n, step, 17), ... -- until it is not.  The reference draws
+ *      std::uniform_int_distribution (exact as well).
+ * One Philox block per two steps is where the resampler's time goes (~50 of its ~75 VALU instructions per step were
+ * the ten rounds): profiles/r03_pmc_mh.md. */
+static inline uint32_t mh_tn(uint32_t N) { return (uint32_t)(0u - N) % N; }
+
+static inline uint32_t mh_index(uint32_t b, uint32_t i, uint32_t n, uint32_t step, const uint32_t key[2], uint32_t N,
+                                uint32_t tN)
+{
+  uint64_t m = (uint64_t)b * N;
+  if ((uint32_t)m < tN) {
+    for (uint32_t q = 0;; ++q) {
+      uint32_t ctr[4] = {i, n, step, 16u + q}, r[4];
+      oracle_philox4x32_10(ctr, key, r);
+      int found = 0;
+      for (int c = 0; c < 4 && !found; ++c) {
+        m = (uint64_t)r[c] * N;
+        found = (uint32_t)m >= tN;
+      }
+      if (found) break;
+    }
+  }
+  return (uint32_t)(m >> 32);
+}
+
+static inline int mh_accept(uint32_t a, double r, uint32_t i, uint32_t n, uint32_t step, const uint32_t key[2])
+{
+  if (r != r) return 0;
+  const double lo = (double)a * 0x1.0p-32, hi = lo + 0x1.0p-32; /* both exact */
+  if (hi <= r) return 1;
+  if (lo > r) return 0;
+  uint32_t ctr[4] = {i, n, step, 7u}, x[4];
+  oracle_philox4x32_10(ctr, key, x);
+  return u01_53(x[0], x[1]) <= r * 0x1.0p32 - (double)a; /* r 2^32 in [a, a + 1]: the difference is exact */
+}
+
 /* chains [first, first + count) of the N: a[i - first] (what one rank of a sharded resample computes) */
 ORACLE_API void oracle_metropolis_range(uint32_t *a, const double *w, uint32_t N, uint32_t B,
                                         uint64_t seed, uint32_t step, uint32_t first, uint32_t count)
 {
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  const uint32_t tN = mh_tn(N);
 #pragma omp parallel for schedule(static)
   for (uint32_t c = 0; c < count; ++c) {
     const uint32_t i = first + c;
     uint32_t k = i;
     double wk = w[k];
+    uint32_t r[4] = {0, 0, 0, 0};
     for (uint32_t n = 0; n < B; ++n) {
-      uint32_t ctr[4] = {i, n, step, 1u}, r[4];
-      oracle_philox4x32_10(ctr, key, r);
-      double u = u01_53(r[0], r[1]);
-      uint32_t j = uint_below(r[2], r[3], N);
+      if ((n & 1u) == 0) {
+        uint32_t ctr[4] = {i, n >> 1, step, 1u};
+        oracle_philox4x32_10(ctr, key, r);
+      }
+      const uint32_t ua = r[2 * (n & 1u)];
+      const uint32_t j = mh_index(r[2 * (n & 1u) + 1], i, n, step, key, N, tN);
       double wj = w[j];
-      if (u <= wj / wk) { k = j; wk = wj; }
+      if (mh_accept(ua, wj / wk, i, n, step, key)) { k = j; wk = wj; }
     }
     a[c] = k;
   }
@@ -437,22 +487,26 @@ static double exp_nonpos(double t)
 }
 
 /* The Metropolis chain over log-weights: the reference's test (src/samplers.cpp:27-31) with
- * w = exp(lw), i.e. u <= exp(lw[j] - lw[k]); a non-negative difference always accepts (u < 1). */
+ * w = exp(lw), i.e. u <= exp(lw[j] - lw[k]); a non-negative difference always accepts (u < 1).  Draws as above. */
 ORACLE_API void oracle_metropolis_log(uint32_t *a, const double *lw, uint32_t N, uint32_t B,
                                       uint64_t seed, uint32_t step)
 {
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  const uint32_t tN = mh_tn(N);
 #pragma omp parallel for schedule(static)
   for (uint32_t i = 0; i < N; ++i) {
     uint32_t k = i;
     double lk = lw[k];
+    uint32_t r[4] = {0, 0, 0, 0};
     for (uint32_t n = 0; n < B; ++n) {
-      uint32_t ctr[4] = {i, n, step, 1u}, r[4];
-      oracle_philox4x32_10(ctr, key, r);
-      double u = u01_53(r[0], r[1]);
-      uint32_t j = uint_below(r[2], r[3], N);
+      if ((n & 1u) == 0) {
+        uint32_t ctr[4] = {i, n >> 1, step, 1u};
+        oracle_philox4x32_10(ctr, key, r);
+      }
+      const uint32_t ua = r[2 * (n & 1u)];
+      const uint32_t j = mh_index(r[2 * (n & 1u) + 1], i, n, step, key, N, tN);
       double lj = lw[j], t = lj - lk;
-      if (t >= 0.0 || u <= exp_nonpos(t)) { k = j; lk = lj; }
+      if (t >= 0.0 || mh_accept(ua, exp_nonpos(t), i, n, step, key)) { k = j; lk = lj; }
     }
     a[i] = k;
   }
@@ -553,7 +607,7 @@ static double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, const
   return 2.0 * g * boost;
 }
 
-ORACLE_API int oracle_rng_contract(void) { return 2; }
+ORACLE_API int oracle_rng_contract(void) { return 3; }
 
 /* chi^2 draws of components [0, d) of `count` particles starting at `first` (tests/test_distributions.py holds
  * them against the exact chi^2_nu law; the kernels never see this) */

@@ -159,7 +159,7 @@ def check_chi_square(draw):
 
 
 def test_oracle_chi_square_law(oracle):
-    assert oracle.rng_contract() == 2
+    assert oracle.rng_contract() == 3
     check_chi_square(lambda n, d, nu, seed: oracle.chi_square(n, d, nu, seed=seed, step=3))
 
 

@@ -418,6 +418,43 @@ def test_log_weight_resampler_bit_exact(cs, oracle, N, B):
         assert np.array_equal(part.cpu().numpy().astype(np.uint32), want[first:first + count])
 
 
+def test_resampler_contract3_rare_paths(cs, oracle):
+    """RNG contract 3's two completions, forced (a random run meets them once in 2^32 resp. 2^12 steps):
+    (1) the ratio INSIDE the 32-bit cell of u -- w[j] / w[k] = (a + 1/2) 2^-32 for the very a the step draws -- so that
+        the next 53 bits decide: the plain chain (N = 2), the truncated-table chain (N = 1e6, where the undecided step
+        falls through to the exact test) and the log-weight chain;
+    (2) index candidates redrawn by Lemire's rejection: N = 3 * 2^20 redraws one in 4096.
+    All bit-identical to the oracle (whose own exact-arithmetic restatement is tests/test_oracle.py)."""
+    hits = 0
+    for seed in range(40):
+        step = 2
+        r = oracle.philox4x32_10([0, 0, step, 1], [seed, 0])
+        a, j = int(r[0]), (int(r[1]) * 2) >> 32
+        if j != 1:
+            continue
+        w = np.array([1.0, (a + 0.5) * 2.0 ** -32])
+        assert np.array_equal(cs.Sampler.metropolis_hastings(w, 2, t=step, B=1, seed=seed), oracle.metropolis(w, 1, seed, step))
+        lw = np.log(w)
+        assert np.array_equal(cs.Sampler.metropolis_hastings_log(lw, 2, t=step, B=1, seed=seed), oracle.metropolis_log(lw, 1, seed, step))
+        hits += 1
+    assert hits >= 5
+    # the truncated-table chain: chain 0's first proposal meets a weight inside its cell
+    N, B, seed, step = 1_000_000, 2, 99, 3
+    r = oracle.philox4x32_10([0, 0, step, 1], [seed, 0])
+    a, j = int(r[0]), (int(r[1]) * N) >> 32
+    w = np.ones(N)
+    if j != 0:
+        w[j] = (a + 0.5) * 2.0 ** -32
+    assert np.array_equal(cs.Sampler.metropolis_hastings(w, N, t=step, B=B, seed=seed), oracle.metropolis(w, B, seed, step))
+    # redraws
+    N = 3 * 2 ** 20
+    w = np.random.default_rng(8).random(N)
+    for B in (1, 10):
+        assert np.array_equal(cs.Sampler.metropolis_hastings(w, N, t=4, B=B, seed=31337), oracle.metropolis(w, B, 31337, step=4))
+    lw = np.log(w)
+    assert np.array_equal(cs.Sampler.metropolis_hastings_log(lw, N, t=4, B=5, seed=31337), oracle.metropolis_log(lw, 5, 31337, step=4))
+
+
 def test_resampler_shards_compose(cs, oracle):
     """Chains [first, first+count) computed separately equal the single launch (global Philox
     indices): what the multi-GPU path relies on."""

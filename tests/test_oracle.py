@@ -110,23 +110,98 @@ def test_resampler_matches_golden(oracle, golden, name, B):
     assert a.max() < w.shape[0]
 
 
+def _python_chain(oracle, w, N, B, seed, step, chains=None):
+    """Pure-Python restatement of src/samplers.cpp:21-35 under RNG contract 3, in exact integer / rational arithmetic
+    (Fraction), sharing nothing with the C oracle but the Philox blocks: one block per two steps; u = the uniform real
+    whose leading 32 bits are word 2h, completed by 53 more bits (domain 7) only when the ratio lies inside its
+    cell; j by Lemire's unbiased multiply-and-reject on word 2h + 1 (redraws: domains 16, 17, ...)."""
+    from fractions import Fraction
+    key = [seed & 0xFFFFFFFF, seed >> 32]
+    tN = (2 ** 32 - N) % N
+    expect, refined, redrawn = [], 0, 0
+    for i in (range(N) if chains is None else chains):
+        k = i
+        for n in range(B):
+            r = oracle.philox4x32_10([i, n >> 1, step, 1], key)
+            a, b = int(r[2 * (n & 1)]), int(r[2 * (n & 1) + 1])
+            m = b * N
+            if (m & 0xFFFFFFFF) < tN:
+                redrawn += 1
+                q, found = 0, False
+                while not found:
+                    x = oracle.philox4x32_10([i, n, step, 16 + q], key)
+                    for c in range(4):
+                        m = int(x[c]) * N
+                        if (m & 0xFFFFFFFF) >= tN:
+                            found = True
+                            break
+                    q += 1
+            j = m >> 32
+            ratio = w[j] / w[k]                       # the reference's double division
+            if ratio != ratio:
+                continue
+            rr = Fraction(ratio) if np.isfinite(ratio) else (Fraction(10) ** 400 if ratio > 0 else -Fraction(10) ** 400)
+            lo, hi = Fraction(a, 2 ** 32), Fraction(a + 1, 2 ** 32)
+            if hi <= rr:
+                acc = True
+            elif lo > rr:
+                acc = False
+            else:
+                refined += 1
+                x = oracle.philox4x32_10([i, n, step, 7], key)
+                v = Fraction((int(x[0]) << 32 | int(x[1])) >> 11, 2 ** 53)
+                acc = lo + v / 2 ** 32 <= rr          # u = (a + V) 2^-32 <= ratio
+            if acc:
+                k = j
+        expect.append(k)
+    return expect, refined, redrawn
+
+
 def test_resampler_semantics(oracle):
-    # pure-Python restatement of src/samplers.cpp:21-35 on the same Philox stream
     rng = np.random.default_rng(11)
     w = rng.random(50)
     N, B, seed, step = 50, 7, 0xDEADBEEFCAFE, 3
-    key = [seed & 0xFFFFFFFF, seed >> 32]
-    expect = []
-    for i in range(N):
-        k = i
-        for n in range(B):
-            r = oracle.philox4x32_10([i, n, step, 1], key)
-            u = float(((int(r[0]) << 32 | int(r[1])) >> 11) * 2.0 ** -53)
-            j = ((int(r[2]) << 32 | int(r[3])) * N) >> 64
-            if u <= w[j] / w[k]:
-                k = j
-        expect.append(k)
+    expect, _, _ = _python_chain(oracle, w, N, B, seed, step)
     assert oracle.metropolis(w, B, seed, step).tolist() == expect
+
+
+def test_resampler_refinement_forced(oracle):
+    """Contract 3's first completion, which a random run meets once in 2^32 steps: the ratio INSIDE u's 32-bit cell
+    (w[1] / w[0] = (a + 1/2) 2^-32 for the very a chain 0's first step draws), so that the 53 refinement bits decide."""
+    hits = 0
+    for seed in range(40):
+        step = 2
+        r = oracle.philox4x32_10([0, 0, step, 1], [seed, 0])
+        a, j = int(r[0]), (int(r[1]) * 2) >> 32
+        if j != 1:
+            continue  # (a self-proposal: ratio 1, accepted outright)
+        w = np.array([1.0, (a + 0.5) * 2.0 ** -32])
+        expect, refined, _ = _python_chain(oracle, w, 2, 1, seed, step)
+        assert refined >= 1
+        assert oracle.metropolis(w, 1, seed, step).tolist() == expect
+        hits += 1
+    assert hits >= 5
+
+
+def test_resampler_index_redraws(oracle):
+    """Contract 3's second completion: N = 3 * 2^20 leaves tN = 2^20, i.e. one index candidate in 4096 is redrawn
+    (Lemire's rejection); the exact-arithmetic restatement over the first 60000 chains meets a few dozen."""
+    N, B, seed, step = 3 * 2 ** 20, 3, 31337, 4
+    w = np.random.default_rng(8).random(N)
+    sub = 60000
+    expect, _, redrawn = _python_chain(oracle, w, N, B, seed, step, chains=range(sub))
+    assert redrawn >= 10
+    assert oracle.metropolis(w, B, seed, step)[:sub].tolist() == expect
+
+
+def test_resampler_index_is_uniform(oracle):
+    """B = 1 over equal weights always accepts: the ancestors ARE the index draws."""
+    from scipy import stats
+    N = 1000
+    counts = np.zeros(N)
+    for seed in range(20):
+        counts += np.bincount(oracle.metropolis(np.ones(N), 1, seed=seed), minlength=N)
+    assert stats.chisquare(counts).pvalue > 1e-3
 
 
 def test_resampler_targets_weights(oracle):
