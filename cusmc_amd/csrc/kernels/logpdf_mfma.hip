@@ -66,6 +66,9 @@ namespace {
 const unsigned char kNb4CodeObject[] = {
 #include "logpdf_nb4_co.inc"
 };
+const unsigned char kNb4CodeObjectB0[] = {  // assembled with BIRTH = 0 (A/B runs: CUSMC_NB4_ASM=2)
+#include "logpdf_nb4_b0_co.inc"
+};
 struct AsmKernel {
   std::atomic<int> state{0};  // 0 not tried, 1 ready, 2 unavailable
   hipModule_t mod = nullptr;
@@ -73,6 +76,11 @@ struct AsmKernel {
 };
 AsmKernel g_nb4[64];
 std::atomic_flag g_nb4_lock = ATOMIC_FLAG_INIT;
+int nb4_mode()
+{
+  static const int mode = [] { const char *e = getenv("CUSMC_NB4_ASM"); return e ? atoi(e) : 1; }();  // 0: compiled kernel, 2: BIRTH = 0
+  return mode;
+}
 
 hipFunction_t nb4_function()
 {
@@ -85,7 +93,7 @@ hipFunction_t nb4_function()
     st = k.state.load(std::memory_order_acquire);
     if (st == 0) {
       st = 2;
-      if (hipModuleLoadData(&k.mod, kNb4CodeObject) == hipSuccess &&
+      if (hipModuleLoadData(&k.mod, nb4_mode() == 2 ? kNb4CodeObjectB0 : kNb4CodeObject) == hipSuccess &&
           hipModuleGetFunction(&k.fn, k.mod, "cusmc_logpdf_nb4_asm") == hipSuccess)
         st = 1;
       (void)hipGetLastError();
@@ -122,8 +130,7 @@ size_t nb4_pool_bytes() { return 8192 + 2 * 32768; }  // two counter blocks of 3
 static bool launch_nb4_asm(const double *X, int64_t N, int64_t ldx, const double *frags, const Epilogue &ep, double *out,
                            int num_cus, Nb4Pool *pool, hipStream_t stream, hipError_t *err)
 {
-  static const int mode = [] { const char *e = getenv("CUSMC_NB4_ASM"); return e ? atoi(e) : 1; }();  // 0: compiled kernel (A/B)
-  if (mode == 0 || !pool || !pool->dev) return false;
+  if (nb4_mode() == 0 || !pool || !pool->dev) return false;
   const long num_tiles = (N + 15) / 16;
   const long blocks = num_cus;
   if (blocks < 4 || num_tiles < 64 * blocks || num_tiles >= (1L << 31)) return false;  // (a tail pool needs a body, and every one of the 32 counters a wave: 8 b + w covers them from 4 workgroups up)

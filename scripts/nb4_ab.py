@@ -52,11 +52,12 @@ def main():
         return child()
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     extra = dict(kv.split("=", 1) for kv in sys.argv[2:])
-    res = {"0": [], "1": []}
+    modes = ("0", "2", "1") if os.environ.get("NB4_AB_THREE") else ("0", "1")
+    res = {m: [] for m in modes}
     sums = {}
     for r in range(rounds):
-        for mode in ("0", "1"):
-            env = dict(os.environ, NB4_AB_CHILD="1", CUSMC_NB4_ASM=mode, **(extra if mode == "1" else {}))
+        for mode in modes:
+            env = dict(os.environ, NB4_AB_CHILD="1", CUSMC_NB4_ASM=mode, **(extra if mode != "0" else {}))
             out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
             if not line:
@@ -66,10 +67,12 @@ def main():
             res[mode].append(float(med))
             sums.setdefault(mode, s)
             assert sums[mode] == s, "outputs differ between runs of one mode"
-            print("round %d %s: median %.2f us (min %.2f max %.2f)" % (r, "asm     " if mode == "1" else "compiled", float(med), float(lo), float(hi)), flush=True)
-    print("bit-identical outputs at all sizes:", sums["0"] == sums["1"])
-    print("compiled median of medians %.2f us | asm %.2f us %s" % (sorted(res["0"])[len(res["0"]) // 2], sorted(res["1"])[len(res["1"]) // 2], extra or ""))
-    return 0 if sums["0"] == sums["1"] else 2
+            print("round %d %s: median %.2f us (min %.2f max %.2f)" % (r, {"0": "compiled   ", "1": "asm        ", "2": "asm BIRTH=0"}[mode], float(med), float(lo), float(hi)), flush=True)
+    same = all(sums[m] == sums["0"] for m in modes)
+    print("bit-identical outputs at all sizes:", same)
+    mid = lambda v: sorted(v)[len(v) // 2]
+    print("median of medians: " + " | ".join("%s %.2f us" % ({"0": "compiled", "1": "asm", "2": "asm BIRTH=0"}[m], mid(res[m])) for m in modes), extra or "")
+    return 0 if same else 2
 
 
 if __name__ == "__main__":
