@@ -8,7 +8,7 @@ d, counter = sys.argv[1], sys.argv[2]
 vals = {}
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and "cusmc::" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and "cusmc" in r["Kernel_Name"]:
             k = r["Kernel_Name"]
             k = k if len(k) < 100 else k[:97] + "..."
             vals.setdefault(k, []).append(float(r["Counter_Value"]))

@@ -23,7 +23,7 @@ def main(d):
     # the 20 TIMED dispatches themselves: bench.py runs 595 settle + 5 warm-up launches of the headline kernel,
     # then the timed 20 (then the strong-scaling leg's 800); rocprof's duration excludes the ~2.5 us between launches
     for f in glob.glob(d + "/kt/**/*kernel_trace.csv", recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "logpdf_mfma_kernel<4, true, false, 0, 1, false>" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if "cusmc_logpdf_nb4_asm" in r["Kernel_Name"] or "logpdf_mfma_kernel<4, true, false, 0, 1, false>" in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         if len(rows) >= 620:
             win = rows[600:620]
@@ -38,7 +38,7 @@ def main(d):
         print("\n## --kernel-trace --stats (python3 scripts/bench_configs.py: the other BASELINE configs)\n")
         print("| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|")
         for r in csv.DictReader(open(f)):
-            if "cusmc::" not in r["Name"]:
+            if "cusmc" not in r["Name"]:
                 continue
             print("| %s | %s | %.1f | %.1f | %.1f |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                       float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
@@ -46,7 +46,7 @@ def main(d):
         for f in glob.glob(d + "/%s/**/*counter_collection.csv" % counter.split("_")[0].lower(), recursive=True):
             vals = {}
             for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] == counter and "cusmc::" in r["Kernel_Name"]:
+                if r["Counter_Name"] == counter and "cusmc" in r["Kernel_Name"]:
                     vals.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
             print("\n## --pmc %s (KiB per dispatch, raw counter)\n" % counter)
             for k, v in vals.items():
