@@ -42,6 +42,10 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
     uint32_t first, uint32_t count, uint32_t *__restrict__ a_out, double *__restrict__ X_out,
     double *__restrict__ w_out, typename ShardArg<SH>::type sh)
 {
+  __shared__ ChiQueue chi_queues[MVT ? 4 : 1];  // Student-t: a wave's open chi^2 draws, shared out over its lanes
+  ChiQueue *const chi_q = MVT ? &chi_queues[threadIdx.x >> 6] : nullptr;
+  if (MVT && (threadIdx.x & 63) == 0) chi_q->count = 0;
+  if (MVT) chi_wave_fence();
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
     const uint32_t i = first + t;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(
     }
     double chi[D];
     if (MVT)  // the particle's D chi^2 draws together (smallops.h: chi_pair_batch)
-      chi_square_all<D>(chi_setup(nu), i, step, k0, k1, chi);
+      chi_square_all<D>(chi_setup(nu), i, step, k0, k1, chi, chi_q);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       double s = 0.0;

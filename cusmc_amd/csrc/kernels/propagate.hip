@@ -180,6 +180,10 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
     }
     return;
   }
+  __shared__ ChiQueue chi_queues[4];  // one per wave: its open chi^2 draws, shared out over its lanes (smallops.h)
+  ChiQueue *const chi_q = &chi_queues[threadIdx.x >> 6];
+  if ((threadIdx.x & 63) == 0) chi_q->count = 0;
+  chi_wave_fence();
   for (uint32_t il = blockIdx.x * rows_per_block + lane_row; il < count; il += gridDim.x * rows_per_block) {
     const uint32_t i = first + il;
     const long anc = gdiag ? (a ? (long)a[il] : (long)i) : 0;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
           }
         }
         double chi[2 * PPL];
-        chi_pair_batch<PPL>(cs, i, step, k0, k1, [&](int c) { return pr0 + c * pw; }, [&](int c) { return pr0 + c * pw < pairs; }, chi);
+        chi_pair_batch<PPL>(cs, i, step, k0, k1, [&](int c) { return pr0 + c * pw; }, [&](int c) { return pr0 + c * pw < pairs; }, chi, chi_q);
 #pragma unroll
         for (int q = 0; q < PPL; ++q)
 #pragma unroll
@@ -316,6 +320,10 @@ __global__ __launch_bounds__(256) void propagate_small_kernel(
     double scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t domain, uint32_t first,
     uint32_t count, double *__restrict__ X_out)
 {
+  __shared__ ChiQueue chi_queues[MVT ? 4 : 1];  // Student-t: a wave's open chi^2 draws, shared out over its lanes
+  ChiQueue *const chi_q = MVT ? &chi_queues[threadIdx.x >> 6] : nullptr;
+  if (MVT && (threadIdx.x & 63) == 0) chi_q->count = 0;
+  if (MVT) chi_wave_fence();
   const uint32_t stride = gridDim.x * 256u;
   for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < count; t += stride) {
     const uint32_t i = first + t;
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void propagate_small_kernel(
     }
     double chi[D];
     if (MVT)  // the particle's D chi^2 draws together (smallops.h: chi_pair_batch)
-      chi_square_all<D>(chi_setup(nu), i, step, k0, k1, chi);
+      chi_square_all<D>(chi_setup(nu), i, step, k0, k1, chi, chi_q);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       double s = 0.0;

@@ -76,6 +76,9 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
   if (HAS_M0 && threadIdx.x < D) sG[threadIdx.x] = (int)threadIdx.x < d ? m0[threadIdx.x] : 0.0;
   if (DIAG_G && threadIdx.x < D) sG[threadIdx.x] = (int)threadIdx.x < d ? fragsG[threadIdx.x] : 0.0;
   if (threadIdx.x == 0) *sNext = 0;
+  // Student-t: one queue per wave for its open chi^2 draws (smallops.h: ChiQueue), behind the tile counter
+  ChiQueue *const chi_q = (MVT && HAS_Q) ? reinterpret_cast<ChiQueue *>(sNext + 2) + (threadIdx.x >> 6) : nullptr;
+  if ((MVT && HAS_Q) && (threadIdx.x & 63) == 0) chi_q->count = 0;
   __syncthreads();
 
   const ChiSquare cs = chi_setup(MVT ? nu : 2.0f);
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
           if (cb % GB == 0) {
             const int cb0 = cb;
             chi_square_clayout<GB>(cs, gi, step, k0, k1, h, [&](int b) { return 16 * (cb0 + b); },
-                                   [&](int b, int j) { return cb0 + b < NB && (!PAD || j < d); }, chi);
+                                   [&](int b, int j) { return cb0 + b < NB && (!PAD || j < d); }, chi, chi_q);
           }
         }
 #pragma unroll
@@ -211,7 +214,8 @@ static hipError_t launch_pm(float nu, const double *X_prev, const uint32_t *a, c
 {
   constexpr int NFRAG = 4 * NB * NB;
   constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0, DIAG_G = MODE == 4;
-  const size_t lds_bytes = (size_t)((HAS_Q ? NFRAG * 64 : 0) + (HAS_G ? NFRAG * 64 : (HAS_M0 || DIAG_G ? 16 * NB : 0)) + 2) * sizeof(double);
+  const size_t lds_bytes = (size_t)((HAS_Q ? NFRAG * 64 : 0) + (HAS_G ? NFRAG * 64 : (HAS_M0 || DIAG_G ? 16 * NB : 0)) + 2) * sizeof(double) +
+                           ((MVT && HAS_Q) ? 8 * sizeof(ChiQueue) : 0);
   auto kern = propagate_mfma_kernel<NB, MVT, MODE, PAD>;
   static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;

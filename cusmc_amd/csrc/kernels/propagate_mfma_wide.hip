@@ -55,7 +55,7 @@ bool propagate_mfma_wide_supported(int d, const void *X_prev, const void *X_out)
 size_t propagate_wide_lds_bytes(int nb, bool mvt)
 {
   const size_t slabs = (size_t)nb * 2 * kWideTiles * 1024, park = 8 * 16384;
-  return mvt && park > slabs ? park : slabs;
+  return (mvt && park > slabs ? park : slabs) + (mvt ? 8 * sizeof(ChiQueue) : 0);  // (+ a queue per wave for its open chi^2 draws)
 }
 
 // MODE 0: x = [diag(c)] Q xi + m0     (tail = m0, d doubles)
@@ -90,6 +90,10 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // Student-t: this wave's queue for its open chi^2 draws (smallops.h: ChiQueue), behind the slabs / the parking area
+  constexpr size_t kSlabDoubles = (size_t)NB * 2 * T * 128 > 8 * 2048 ? (size_t)NB * 2 * T * 128 : 8 * 2048;
+  ChiQueue *const chi_q = MVT ? reinterpret_cast<ChiQueue *>(lds + kSlabDoubles) + w : nullptr;
+  if (MVT && lane == 0) chi_q->count = 0;  // (the first use lies behind several __syncthreads())
   const int p = lane & 15, h = lane >> 4;
   const ChiSquare cs = chi_setup(MVT ? nu : 2.0f);
   // this wave's output blocks: w, and w + 8 if there is one
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
         const uint32_t gi = first + (uint32_t)(local < (long)count ? local : (long)count - 1);
         double chi[8];
         chi_square_clayout<2>(cs, gi, step, k0, k1, h, [&](int b) { return 16 * (b ? cb1 : cb0); },
-                              [&](int b, int j) { return (b == 0 || two) && (!PAD || j < d); }, chi);
+                              [&](int b, int j) { return (b == 0 || two) && (!PAD || j < d); }, chi, chi_q);
 #pragma unroll
         for (int c = 0; c < 8; c += 2) {
           v2d *q = park + (((c >> 2) * T + t) * 2 + ((c >> 1) & 1)) * 64;

@@ -203,11 +203,31 @@ static __device__ __forceinline__ void chi_boost_pair(const ChiSquare &cs, uint3
   b0 = pow(1.0 - u01_53(r.x, r.y), cs.inv_a);
   b1 = pow(1.0 - u01_53(r.z, r.w), cs.inv_a);
 }
+// The open draws of a WAVE, resolved together.  After the branch-free first pass ~8 % of the draws are still open:
+// with 8 .. 16 draws per lane that is one lane in two, and a wave that lets every lane walk its own takes as many
+// trips through the full loop as its unluckiest lane has open draws (3 - 4 of the ~41 a wave of 512 draws leaves) --
+// more time than the first pass itself.  Instead the lanes pool them in a per-wave LDS queue and share them out
+// again, one per ACTIVE lane and trip: 41 open draws are one trip.  (Draws that do not fit the queue stay with
+// their lane.)  Same counters, same results: who computes a draw does not enter it.
+struct ChiQueue {
+  static constexpr int CAP = 64;
+  uint32_t count, pad;
+  uint32_t item[CAP][2];  // (particle, 2 p + e)
+  double result[CAP];
+};
+static __device__ __forceinline__ void chi_wave_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (LDS is in order per wave: this is s_waitcnt lgkmcnt(0) and a compiler barrier)
+  __builtin_amdgcn_wave_barrier();
+}
+
 // chi[2 c + e] = chi^2_nu draw of component 2 pof(c) + e for the c < KP with live(c); pof / live are evaluated
 // for run-time c as well (closed forms, not tables: no dynamically indexed registers).  A dead pair gets 1.
+// q: this WAVE's queue in LDS (count zeroed before the first call), or NULL.
 template <int KP, typename POf, typename Live>
 static __device__ __forceinline__ void chi_pair_batch(const ChiSquare &cs, uint32_t particle, uint32_t step, uint32_t k0,
-                                                      uint32_t k1, POf pof, Live live, double (&chi)[2 * KP])
+                                                      uint32_t k1, POf pof, Live live, double (&chi)[2 * KP],
+                                                      ChiQueue *q = nullptr)
 {
   static_assert(KP <= 16, "one pending bit per draw");
 #pragma unroll
@@ -246,7 +266,48 @@ static __device__ __forceinline__ void chi_pair_batch(const ChiSquare &cs, uint3
       chi[2 * cc + 1] = cc == c ? g1 : chi[2 * cc + 1];
     }
   }
-  while (pend) {  // one open draw per lane per trip
+  if (q) {
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    const uint32_t nact = (uint32_t)__builtin_popcountll(act);
+    const uint32_t n_mine = (uint32_t)__builtin_popcount(pend);
+    uint32_t base = 0;
+    if (n_mine) base = __hip_atomic_fetch_add(&q->count, n_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t rest = pend, k = 0;
+    while (rest) {  // publish what fits
+      const int c = __builtin_ctz(rest);
+      rest &= rest - 1u;
+      const uint32_t slot = base + k++;
+      if (slot < (uint32_t)ChiQueue::CAP) {
+        q->item[slot][0] = particle;
+        q->item[slot][1] = ((uint32_t)pof(c >> 1) << 1) | (uint32_t)(c & 1);
+      }
+    }
+    chi_wave_fence();
+    uint32_t total = __hip_atomic_load(&q->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    total = total < (uint32_t)ChiQueue::CAP ? total : (uint32_t)ChiQueue::CAP;
+    for (uint32_t idx = rank; idx < total; idx += nact) {  // one open draw per ACTIVE lane per trip
+      const uint32_t ip = q->item[idx][0], pe = q->item[idx][1];
+      q->result[idx] = chi_loop(cs, ip, pe >> 1, pe & 1u, step, k0, k1);
+    }
+    chi_wave_fence();
+    rest = pend, k = 0;
+    while (rest) {  // collect
+      const int c = __builtin_ctz(rest);
+      rest &= rest - 1u;
+      const uint32_t slot = base + k++;
+      if (slot < (uint32_t)ChiQueue::CAP) {
+        const double g = q->result[slot];
+        pend &= ~(1u << c);
+#pragma unroll
+        for (int cc = 0; cc < 2 * KP; ++cc) chi[cc] = cc == c ? g : chi[cc];
+      }
+    }
+    chi_wave_fence();
+    if (rank == 0) __hip_atomic_store(&q->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    chi_wave_fence();
+  }
+  while (pend) {  // one open draw per lane per trip (no queue, or its overflow)
     const int c = __builtin_ctz(pend);
     pend &= pend - 1u;
     const double g = chi_loop(cs, particle, (uint32_t)pof(c >> 1), (uint32_t)(c & 1), step, k0, k1);
@@ -270,11 +331,11 @@ static __device__ __forceinline__ void chi_pair_batch(const ChiSquare &cs, uint3
 // the D draws of one particle held by one lane (lane = particle kernels): chi[j], j < D
 template <int D>
 static __device__ __forceinline__ void chi_square_all(const ChiSquare &cs, uint32_t particle, uint32_t step, uint32_t k0,
-                                                      uint32_t k1, double (&chi)[D])
+                                                      uint32_t k1, double (&chi)[D], ChiQueue *q = nullptr)
 {
   constexpr int KP = (D + 1) / 2;
   double tmp[2 * KP];
-  chi_pair_batch<KP>(cs, particle, step, k0, k1, [](int c) { return c; }, [](int) { return true; }, tmp);
+  chi_pair_batch<KP>(cs, particle, step, k0, k1, [](int c) { return c; }, [](int) { return true; }, tmp, q);
 #pragma unroll
   for (int j = 0; j < D; ++j) chi[j] = tmp[j];
 }
@@ -294,12 +355,12 @@ static __device__ __forceinline__ double chi_square_for(uint32_t particle, uint3
 template <int NBLK, typename BlkOf, typename LiveJ>
 static __device__ __forceinline__ void chi_square_clayout(const ChiSquare &cs, uint32_t particle, uint32_t step,
                                                           uint32_t k0, uint32_t k1, int h, BlkOf blk, LiveJ livej,
-                                                          double (&out)[4 * NBLK])
+                                                          double (&out)[4 * NBLK], ChiQueue *q = nullptr)
 {
   const int e = h & 1, hb = h - e;
   auto jof = [&](int c) { return blk(c >> 1) + hb + 4 * (2 * e + (c & 1)); };  // the even component of pair c
   double mine[4 * NBLK];
-  chi_pair_batch<2 * NBLK>(cs, particle, step, k0, k1, [&](int c) { return jof(c) >> 1; }, [&](int c) { return livej(c >> 1, jof(c)); }, mine);
+  chi_pair_batch<2 * NBLK>(cs, particle, step, k0, k1, [&](int c) { return jof(c) >> 1; }, [&](int c) { return livej(c >> 1, jof(c)); }, mine, q);
 #pragma unroll
   for (int c = 0; c < 2 * NBLK; ++c) {
     const double keep = e ? mine[2 * c + 1] : mine[2 * c], give = e ? mine[2 * c] : mine[2 * c + 1];
