@@ -1,4 +1,4 @@
-// Batched multivariate Normal / Student-t log-density, any d <= 319, fp64 -- the shape-agnostic
+// Batched multivariate Normal / Student-t log-density, any d (<= 639), fp64 -- the shape-agnostic
 // path (d not a multiple of 16, unaligned or odd-stride batches, tiny d).  Same contract as
 // kernels/logpdf_mfma.hip:   z = bias + M (x - shift),  q = z.z,  out = epilogue(q);
 // same reference functions replaced (src/statistics.cc.cpp:171-196, :295-324;
@@ -139,7 +139,7 @@ static hipError_t launch_small(const double *X, int64_t N, int64_t ldx, bool tri
   return hipGetLastError();
 }
 
-bool generic_supported(int d) { return d >= 1 && (size_t)64 * (d | 1) * 8 <= 160 * 1024; }
+bool generic_supported(int d) { return d >= 1 && (size_t)32 * (d | 1) * 8 <= 160 * 1024; }  // (d <= 639; CUSMC_MAX_DIM is below that)
 
 template <int T>
 static hipError_t launch_t(const double *X, int64_t N, int64_t ldx, int d, bool tri,
@@ -180,7 +180,9 @@ hipError_t launch_logpdf_generic(const double *X, int64_t N, int64_t ldx, int d,
     return launch_t<256>(X, N, ldx, d, tri, M, shift, bias, ep, out, num_cus, stream);
   if (128 * row_bytes <= 64 * 1024)
     return launch_t<128>(X, N, ldx, d, tri, M, shift, bias, ep, out, num_cus, stream);
-  return launch_t<64>(X, N, ldx, d, tri, M, shift, bias, ep, out, num_cus, stream);
+  if (64 * row_bytes <= 160 * 1024)
+    return launch_t<64>(X, N, ldx, d, tri, M, shift, bias, ep, out, num_cus, stream);
+  return launch_t<32>(X, N, ldx, d, tri, M, shift, bias, ep, out, num_cus, stream);  // (d >= 320: half a wave per tile)
 }
 
 }  // namespace cusmc

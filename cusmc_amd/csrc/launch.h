@@ -96,7 +96,7 @@ hipError_t launch_logpdf_mfma_wide(const double *X, int64_t N, int64_t ldx, int 
                                    const double *bias, const Epilogue &ep, double *out,
                                    int num_cus, hipStream_t stream);
 
-// --- kernels/logpdf_generic.hip : any d <= 319, lane = particle --------------------------------
+// --- kernels/logpdf_generic.hip : any d <= 639, lane = particle --------------------------------
 bool generic_supported(int d);
 hipError_t launch_logpdf_generic(const double *X, int64_t N, int64_t ldx, int d, bool tri,
                                  const double *M, const double *shift, const double *bias,

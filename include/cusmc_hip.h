@@ -46,7 +46,11 @@ extern "C" {
 #define CUSMC_ENODEVICE 4 /* no usable gfx950 device                                          */
 #define CUSMC_ERANGE 5    /* size beyond what the kernels support (d > CUSMC_MAX_DIM ...)    */
 
-#define CUSMC_MAX_DIM 256
+/* Largest state dimension.  d <= 256 runs on the tuned kernels; 256 < d <= 384 is served by the
+ * shape-agnostic ones (lane-per-particle log-density, workgroup-per-particle proposal draws): correct, an order of
+ * magnitude slower per particle.  The reference has no limit of its own below the overflow of tgamma() in its Student-t
+ * norm at d ~ 340 (src/statistics.cc.cpp:302, 332-340); log-densities here go through lgamma and do not overflow. */
+#define CUSMC_MAX_DIM 384
 
 /* distribution kinds -- the keys of the reference's Distributions registry
  * ("mvn", "mvt": src/mcmc.cpp:53-58) */

@@ -270,6 +270,57 @@ def test_padded_dimensions(cs, oracle, d, dist):
     D.close()
 
 
+@pytest.mark.parametrize("d", [257, 300, 320, 384])
+def test_beyond_256_dimensions(cs, oracle, d):
+    """256 < d <= CUSMC_MAX_DIM = 384 (the reference has no limit below tgamma's overflow at
+    d ~ 340, src/statistics.cc.cpp:302) is served by the shape-agnostic kernels: log-densities (centred with mu,
+    reweight with a dense F; Normal and Student-t) against the hoisted AND the reference-faithful oracle, proposal
+    draws and a propagate step against the oracle, a small filter run bit-exact in its ancestors."""
+    import torch
+    rng = np.random.default_rng(d)
+    sigma, mu = spd(rng, d), rng.standard_normal(d)
+    N = 333
+    Xh = mu + rng.standard_normal((N, d))
+    X = torch.from_numpy(Xh).cuda()
+    out = torch.empty(N, dtype=torch.float64, device="cuda")
+    F = np.eye(d) + 0.3 * rng.standard_normal((d, d)) / np.sqrt(d)
+    y = rng.standard_normal(d)
+    for dist, nu in (("mvn", 0.0), ("mvt", 4.0)):
+        D = (cs.MultiVariateNormalDistribution(mu, sigma) if dist == "mvn" else cs.MultiVariateTStudentDistribution(mu, sigma, nu))
+        D.ctx.use_torch_stream()
+        D.pdf_dev(X, out)
+        torch.cuda.synchronize()
+        assert rel_err(out.cpu().numpy(), oracle.logpdf_hoisted(Xh, mu, sigma, None, dist, nu)) < RTOL
+        faithful = oracle.pdf_batch(Xh[:6], mu, sigma, np.eye(d), dist, nu)
+        if np.all(faithful > 0) and np.all(np.isfinite(faithful)):  # (the reference's density form under/overflows up here)
+            assert rel_err(out[:6].cpu().numpy(), np.log(faithful)) < RTOL
+        D.reweight_dev(X, y, F, out, log=True)
+        torch.cuda.synchronize()
+        assert rel_err(out.cpu().numpy(), oracle.logpdf_hoisted(y[None, :] - Xh @ F.T, None, sigma, None, dist, nu)) < RTOL
+        assert rel_err(D.pdf_batch(Xh), oracle.logpdf_hoisted(Xh, mu, sigma, None, dist, nu)) < RTOL   # host-pointer entry
+        Q = oracle.eigen_sqrt(0.2 * spd(rng, d))
+        got = D.sample(Q, 200, count=50, seed=42, step=6)
+        want, _ = oracle.initialize(50, mu, Q, dist, nu, 1.0, seed=42, step=6)
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+        G = 0.9 * np.eye(d) + 0.3 * rng.standard_normal((d, d)) / np.sqrt(d)
+        a = rng.integers(0, N, N).astype(np.uint32)
+        Xo = torch.empty(N, d, dtype=torch.float64, device="cuda")
+        cs.api.propagate_dev(X, torch.from_numpy(a.astype(np.int32)).cuda(), G, Q, Xo, dist, nu, 1.0, seed=7, step=3, ctx=D.ctx)
+        torch.cuda.synchronize()
+        assert np.allclose(Xo.cpu().numpy(), oracle.propagate(Xh, a, G, Q, dist, nu, 1.0, seed=7, step=3), rtol=1e-9, atol=1e-9)
+        D.close()
+    T, Np = 3, 64
+    Y = np.cumsum(0.1 * rng.standard_normal((d, T)), axis=1)
+    I = np.eye(d)
+    res = cs.run(Np, d, T, Y, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, 0.0, "metropolis", "mvn", seed=5, return_ancestors=True)
+    Xr, wr, ar = oracle.pf_run(Y.T, Np, np.zeros(d), I, I, 0.9 * I, 0.5 * I, 0.1 * I, "mvn", 0.0, B=10, seed=5, hoisted=True)
+    assert np.array_equal(res["ancestors"], ar) and np.allclose(res["posterior_x"], Xr, atol=1e-9)
+    with pytest.raises(cs.CusmcError) as e:
+        cs.MultiVariateNormalDistribution(np.zeros(385), np.eye(385))
+    from cusmc_amd import _lib
+    assert e.value.code == _lib.ERANGE
+
+
 @pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 6))
 def test_logpdf_random_shapes(cs, oracle, seed):
     """Dispatch fuzz: random d in [1, 256] (CUSMC_MAX_DIM), random N, row stride, base alignment, distribution and
