@@ -393,9 +393,21 @@ def main():
         if dist_on:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         mh_s = float(tm.item())
-        mh = {"steps_per_s": n_total * MH_B / mh_s, "ms_per_resample": mh_s * 1e3,
+        sps = n_total * MH_B / mh_s
+        # Yardstick (counters in profiles/r03_pmc_mh.md): the chain is bound by the rate of its random
+        # gathers -- one L2 request per lane and step (TCC_REQ / step = 0.96), 2.65e11 / s with every SIMD loaded --
+        # not by HBM and not by VALU issue: 50 VALU instructions per wave-step (SQ_INSTS_VALU), ~270 cycles at the
+        # measured issue costs, against the cycles a SIMD spends per wave-step at this rate.
+        cyc_per_wave_step = 2.3e9 * 65536.0 / (sps / world)
+        mh = {"steps_per_s": sps, "ms_per_resample": mh_s * 1e3,
               "workload": "metropolis_hastings %d x N=%d chains, B=%d iters, weights = d=%d MVN densities%s"
-                          % (world, MH_N, MH_B, MH_D, "" if world == 1 else "; all-gather of the weight shards timed")}
+                          % (world, MH_N, MH_B, MH_D, "" if world == 1 else "; all-gather of the weight shards timed"),
+              "bound": "L2 gather requests (one per lane-step)",
+              "gather_requests_per_s_per_gpu": sps / world, "gather_saturated_requests_per_s": 2.65e11,
+              "gather_frac_of_saturated": sps / world / 2.65e11,
+              "gather_useful_GBps_per_gpu": 8.0 * sps / world / 1e9, "gather_sector_GBps_per_gpu": 64.0 * sps / world / 1e9,
+              "valu_instr_per_wave_step": 50, "valu_issue_cycles_per_wave_step": 270,
+              "valu_issue_frac": 270.0 / cyc_per_wave_step}
         d32.close()
     except Exception as exc:  # noqa: BLE001
         mh = aux_failed("mh", exc)
