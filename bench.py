@@ -399,13 +399,18 @@ def main():
         # not by HBM and not by VALU issue: 50 VALU instructions per wave-step (SQ_INSTS_VALU), ~270 cycles at the
         # measured issue costs, against the cycles a SIMD spends per wave-step at this rate.
         cyc_per_wave_step = 2.3e9 * 65536.0 / (sps / world)
+        # (up to 4e5 weights the head of the truncated table -- 40 000 words, 160 KB -- sits in LDS: those gathers
+        # are no L2 requests; resample.hip: metropolis_hi_lds_kernel)
+        lds_frac = min(n_total, 40000) / n_total if (n_total <= 400000 and 90000 <= MH_N <= 262144) else 0.0
+        l2_req = (1.0 - lds_frac) * sps / world
         mh = {"steps_per_s": sps, "ms_per_resample": mh_s * 1e3,
               "workload": "metropolis_hastings %d x N=%d chains, B=%d iters, weights = d=%d MVN densities%s"
                           % (world, MH_N, MH_B, MH_D, "" if world == 1 else "; all-gather of the weight shards timed"),
-              "bound": "L2 gather requests (one per lane-step)",
-              "gather_requests_per_s_per_gpu": sps / world, "gather_saturated_requests_per_s": 2.65e11,
-              "gather_frac_of_saturated": sps / world / 2.65e11,
-              "gather_useful_GBps_per_gpu": 8.0 * sps / world / 1e9, "gather_sector_GBps_per_gpu": 64.0 * sps / world / 1e9,
+              "bound": "L2 gather requests (one per lane-step not served from the LDS head of the table)",
+              "gathers_from_lds_frac": lds_frac,
+              "l2_gather_requests_per_s_per_gpu": l2_req, "l2_gather_saturated_requests_per_s": 2.65e11,
+              "l2_gather_frac_of_saturated": l2_req / 2.65e11,
+              "gather_useful_GBps_per_gpu": 4.0 * sps / world / 1e9, "l2_gather_sector_GBps_per_gpu": 64.0 * l2_req / 1e9,
               "valu_instr_per_wave_step": 50, "valu_issue_cycles_per_wave_step": 270,
               "valu_issue_frac": 270.0 / cyc_per_wave_step}
         d32.close()

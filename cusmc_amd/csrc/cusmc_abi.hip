@@ -846,7 +846,7 @@ CUSMC_EXPORT int cusmc_metropolis_dev(cusmc_ctx *ctx, const double *w_dev, uint3
   if (count == 0) return CUSMC_OK;
   if (!w_dev || !a_dev) return fail(CUSMC_EINVAL, "null weight or ancestor pointer");
   const uint32_t *whi = nullptr;
-  if (cusmc::metropolis_wants_hiwords(N) && B > 1) {
+  if ((cusmc::metropolis_wants_hiwords(N) && B > 1) || cusmc::metropolis_wants_lds_table(N, B, count)) {
     if (int rc = ctx->whi.reserve((size_t)N * 4)) return rc;
     HIP_TRY(cusmc::launch_hiwords(w_dev, N, (uint32_t *)ctx->whi.p, ctx->num_cus, ctx->stream));
     whi = (const uint32_t *)ctx->whi.p;

@@ -488,26 +488,39 @@ static __device__ __forceinline__ void metropolis_step_hi(const double *__restri
   bh = acc ? ah : bh;
 }
 
+// lds_tab / L: the first L entries of whi held in LDS by the calling workgroup (L = 0: none).  The chain is bound by
+// the request rate of its random gathers, one L2 request per lane and step: every gather that lands
+// below L is an LDS read instead -- the same word, so the same index sequence.
 static __device__ __forceinline__ uint32_t metropolis_chain_hi(const double *__restrict__ w,
                                                                const uint32_t *__restrict__ whi, uint32_t N,
                                                                uint32_t B, uint32_t i, uint32_t step,
-                                                               uint32_t k0, uint32_t k1)
+                                                               uint32_t k0, uint32_t k1, const uint32_t *lds_tab = nullptr,
+                                                               uint32_t L = 0)
 {
   const uint32_t tN = mh_tn(N);
+  // (two masked loads under a branch each.  Branch-free -- an LDS read at a clamped index plus a global read that
+  // sends the LDS-resident lanes to word 0 -- measured SLOWER, 422 against 344 us at N = 1e5: the dummy lanes still
+  // cost the vector-memory path their slots)
+  auto word = [&](uint32_t j) -> uint32_t {
+    uint32_t v;
+    if (j < L) v = lds_tab[j];
+    else v = whi[j];
+    return v;
+  };
   uint32_t k = i, bh = whi[i];
   uint32_t n = 0;
   for (; n + 4 <= B; n += 4) {
     const MhDraw4 d = mh_draw4(i, n, step, N, tN, k0, k1);
     uint32_t ah[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) ah[c] = whi[d.j[c]];
+    for (int c = 0; c < 4; ++c) ah[c] = word(d.j[c]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) metropolis_step_hi(w, d.a[c], d.j[c], ah[c], k, bh, i, n + c, step, k0, k1);
   }
   for (; n < B; ++n) {
     uint32_t a, j;
     mh_draw1(i, n, step, N, tN, k0, k1, a, j);
-    metropolis_step_hi(w, a, j, whi[j], k, bh, i, n, step, k0, k1);
+    metropolis_step_hi(w, a, j, word(j), k, bh, i, n, step, k0, k1);
   }
   return k;
 }

@@ -108,6 +108,7 @@ hipError_t launch_logpdf_generic(const double *X, int64_t N, int64_t ldx, int d,
 hipError_t launch_metropolis_log(const double *lw, uint32_t N, uint32_t B, uint64_t seed, uint32_t step,
                                  uint32_t first, uint32_t count, uint32_t *a, int num_cus, hipStream_t stream);
 bool metropolis_wants_hiwords(uint32_t N);  // weight table too big for one XCD's L2
+bool metropolis_wants_lds_table(uint32_t N, uint32_t B, uint32_t count);  // head of the truncated table in LDS (needs whi)
 hipError_t launch_hiwords(const double *w, uint32_t N, uint32_t *whi, int num_cus, hipStream_t stream);
 // whi: high words of w (launch_hiwords), or NULL to gather from the doubles
 hipError_t launch_metropolis(const double *w, const uint32_t *whi, uint32_t N, uint32_t B, uint64_t seed,
