@@ -200,6 +200,42 @@ def test_full_size_properties(cs, oracle, N, d):
     D.close(); D0.close()
 
 
+@pytest.mark.parametrize("N,ldx", [(262_144 + 5, 64), (400_001, 66), (1_000_000, 80), (999_999, 64)])
+def test_assembly_kernel_against_oracle_and_compiled_kernel(cs, oracle, N, ldx):
+    """The hand-written assembly kernel (kernels/logpdf_nb4_gfx950.s: d = 64, zero mean, MVN log-density, N >= 262144):
+    EVERY row against the hoisted oracle, strided rows with NaN in the padding, a ragged last tile -- and bitwise
+    against the compiled kernel, which serves the same rows when they arrive in pieces below the assembly kernel's
+    threshold (its tail pool hands tiles to whichever wave draws the ticket: the arithmetic must not notice).
+    Repeated launches reuse the alternating pool-counter blocks."""
+    import torch
+    d = 64
+    rng = np.random.default_rng(N)
+    sigma = spd(rng, d)
+    g = torch.Generator(device="cuda").manual_seed(N)
+    buf = torch.full((N, ldx), float("nan"), dtype=torch.float64, device="cuda")
+    buf[:, :d] = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+    X = buf[:, :d]
+    D = cs.MultiVariateNormalDistribution(None, sigma)
+    D.ctx.use_torch_stream()
+    out = torch.full((N + 16,), -7.0, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        out[:N].fill_(float("nan"))
+        D.pdf_dev(X, out[:N])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.all(got[N:] == -7.0)
+    want = oracle.logpdf_hoisted(X.cpu().numpy(), None, sigma)
+    assert rel_err(got[:N], want) < RTOL
+    pieces = torch.empty(N, dtype=torch.float64, device="cuda")
+    step = 130_000  # (< 16384 tiles: the compiled kernel)
+    for lo in range(0, N, step):
+        hi = min(N, lo + step)
+        D.pdf_dev(X[lo:hi], pieces[lo:hi])
+    torch.cuda.synchronize()
+    assert torch.equal(pieces, out[:N])
+    D.close()
+
+
 @pytest.mark.parametrize("d,N", [(64, 1), (64, 15), (64, 16), (64, 17), (64, 256 * 16 - 1), (64, 256 * 16), (64, 256 * 16 + 1),
                                  (64, 3 * 256 * 16 - 5), (64, 8 * 256 * 16 + 7), (32, 256 * 16 * 2 + 33), (16, 70_001),
                                  (48, 12_289), (96, 256 * 16 + 9)])
