@@ -133,7 +133,10 @@ static bool launch_nb4_asm(const double *X, int64_t N, int64_t ldx, const double
   if (nb4_mode() == 0 || !pool || !pool->dev) return false;
   const long num_tiles = (N + 15) / 16;
   const long blocks = num_cus;
-  if (blocks < 4 || num_tiles < 64 * blocks || num_tiles >= (1L << 31)) return false;  // (a tail pool needs a body, and every one of the 32 counters a wave: 8 b + w covers them from 4 workgroups up)
+  static const int min_rounds = [] { const char *e = getenv("CUSMC_NB4_MIN_ROUNDS"); return e ? atoi(e) : 16; }();
+  // (a tail pool needs a body -- and the first tile by birth needs 8 rounds --, and every one of the 32 counters a wave:
+  // b / 8 + 4 w covers them from 64 workgroups up)
+  if (blocks < 64 || num_tiles < (long)(min_rounds < 16 ? 16 : min_rounds) * blocks || num_tiles >= (1L << 31)) return false;
   hipFunction_t fn = nb4_function();
   if (!fn) return false;
   static const int pool_rounds = [] { const char *e = getenv("CUSMC_NB4_POOL_ROUNDS"); return e ? atoi(e) : 48; }();
@@ -146,7 +149,8 @@ static bool launch_nb4_asm(const double *X, int64_t N, int64_t ldx, const double
   a.pool = reinterpret_cast<unsigned *>(base + parity * 4096);
   a.pool_other = reinterpret_cast<unsigned *>(base + (parity ^ 1u) * 4096);
   a.stamp_records = base + 8192;
-  a.rounds_dealt = (unsigned)(rounds - (pool_rounds < rounds - 8 ? pool_rounds : 0));
+  const long pooled = pool_rounds < rounds / 3 ? pool_rounds : rounds / 3;  // (at least two thirds of the tiles are dealt)
+  a.rounds_dealt = (unsigned)(rounds - pooled);
   static const bool stamps = [] { const char *e = getenv("CUSMC_NB4_STAMPS"); return e && e[0] && e[0] != '0'; }();
   static std::atomic<unsigned> launches{0};
   a.stamps = stamps && blocks <= 256 ? 1u + (launches.fetch_add(1) & 1u) : 0u;

@@ -200,9 +200,9 @@ def test_full_size_properties(cs, oracle, N, d):
     D.close(); D0.close()
 
 
-@pytest.mark.parametrize("N,ldx", [(262_144 + 5, 64), (400_001, 66), (1_000_000, 80), (999_999, 64)])
+@pytest.mark.parametrize("N,ldx", [(65_536 + 5, 64), (125_000, 64), (262_144 + 5, 64), (400_001, 66), (1_000_000, 80), (999_999, 64)])
 def test_assembly_kernel_against_oracle_and_compiled_kernel(cs, oracle, N, ldx):
-    """The hand-written assembly kernel (kernels/logpdf_nb4_gfx950.s: d = 64, zero mean, MVN log-density, N >= 262144):
+    """The hand-written assembly kernel (kernels/logpdf_nb4_gfx950.s: d = 64, zero mean, MVN log-density, N >= 65536):
     EVERY row against the hoisted oracle, strided rows with NaN in the padding, a ragged last tile -- and bitwise
     against the compiled kernel, which serves the same rows when they arrive in pieces below the assembly kernel's
     threshold (its tail pool hands tiles to whichever wave draws the ticket: the arithmetic must not notice).
@@ -227,7 +227,7 @@ def test_assembly_kernel_against_oracle_and_compiled_kernel(cs, oracle, N, ldx):
     want = oracle.logpdf_hoisted(X.cpu().numpy(), None, sigma)
     assert rel_err(got[:N], want) < RTOL
     pieces = torch.empty(N, dtype=torch.float64, device="cuda")
-    step = 130_000  # (< 16384 tiles: the compiled kernel)
+    step = 60_000  # (< 16 rounds of 256 tiles: the compiled kernel)
     for lo in range(0, N, step):
         hi = min(N, lo + step)
         D.pdf_dev(X[lo:hi], pieces[lo:hi])
