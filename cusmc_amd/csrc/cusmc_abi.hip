@@ -1457,7 +1457,7 @@ int pf_run_single(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T
   if (int rc = cusmc_dist_create(ctx, kind, nullptr, V, d, df, &obs)) return rc;
 
   const size_t slice = (size_t)N * d;
-  DevBuf dX, dw, da;
+  DevBuf dX, dw, da, whi2;
   ObsTable ytab;  // (alive until the stream is drained)
   // The history goes back to the host in chunks of whole time steps WHILE the loop runs (the copy
   // engine is idle otherwise and the 2.4 GB of BASELINE configs[2] take four times longer to
@@ -1480,7 +1480,7 @@ int pf_run_single(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T
     (void)hipStreamSynchronize(ctx->stream);
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     for (hipEvent_t ev : chunk_done) if (ev) (void)hipEventDestroy(ev);
-    dX.release(); dw.release(); da.release(); ytab.dev.release();
+    dX.release(); dw.release(); da.release(); whi2.release(); ytab.dev.release();
     cusmc_dist_destroy(obs);
     return code;
   };
@@ -1514,12 +1514,38 @@ int pf_run_single(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T
     const bool fused = pf_step_is_fused(d, N);
     rc = pf_obs_table(obs, fused, G, Qw.data(), Y, T, F, ytab);
     if (rc) return cleanup(rc);
+    // The fused step carries the resampler's truncated weight table along: the kernel that computes w_t stores its
+    // high words as well (the one-shard form of the sharded step kernel), so the loop has no 6 us table pre-pass per
+    // step.  Two tables in turn; the first from w_0.
+    const bool carry_hi = fused && cusmc::metropolis_wants_hiwords(N) && B > 1;
+    if (carry_hi) {
+      rc = whi2.reserve((size_t)N * 2 * 4);
+      if (rc) return cleanup(rc);
+      if (hipError_t e = cusmc::launch_hiwords(w, N, (uint32_t *)whi2.p, ctx->num_cus, ctx->stream); e != hipSuccess)
+        return cleanup(fail(CUSMC_EHIP, "%s building the weight table", hipGetErrorString(e)));
+    }
     for (uint32_t t = 1; t < T; ++t) {
       const double *w_prev = w + (size_t)(t - 1) * N, *X_prev = X + (size_t)(t - 1) * slice;
       uint32_t *a_t = a + (size_t)t * N;
       double *X_t = X + (size_t)t * slice, *w_t = w + (size_t)t * N;
       const double *shift_t = ytab.shift(obs, t), *bias_t = ytab.bias(obs, t);
-      if (fused) {
+      if (carry_hi) {
+        cusmc::ShardStep st;
+        for (int s2 = 0; s2 < cusmc::kMaxShards; ++s2) {
+          st.x.base[s2] = nullptr;
+          st.x.first[s2] = 0xffffffffu;
+          st.w_dst[s2] = nullptr;
+          st.whi_dst[s2] = nullptr;
+        }
+        st.x.first[cusmc::kMaxShards] = 0xffffffffu;
+        st.x.n = 1;
+        st.x.base[0] = X_prev;
+        st.x.first[0] = 0;
+        st.w_dst[0] = w_t;  // (the same store as w_out's)
+        st.whi_dst[0] = (uint32_t *)whi2.p + (size_t)(t & 1) * N;
+        rc = pf_step_launch(obs, kind, df, w_prev, nullptr, N, B, scale, seed, t, 0, N, a_t, X_t, w_t, CUSMC_OUT_DENSITY,
+                            shift_t, bias_t, &st, (const uint32_t *)whi2.p + (size_t)((t - 1) & 1) * N);
+      } else if (fused) {
         rc = pf_step_launch(obs, kind, df, w_prev, X_prev, N, B, scale, seed, t, 0, N, a_t, X_t, w_t,
                             CUSMC_OUT_DENSITY, shift_t, bias_t);
       } else {
