@@ -453,7 +453,7 @@ def test_resampler_bit_exact_oracle(cs, oracle, N, B):
     assert np.array_equal(a, oracle.metropolis(w, B, seed, step=7))
 
 
-@pytest.mark.parametrize("B,seed", [(2, 1), (10, 99), (37, 12345678901234567)])
+@pytest.mark.parametrize("B,seed", [(2, 1), (10, 99), (37, 12345678901234567), (100, 7)])
 @pytest.mark.parametrize("kind", ["densities", "adversarial"])
 def test_resampler_large_N_truncated_table(cs, oracle, kind, B, seed):
     """N = 1e6 (the weight vector no longer fits one XCD's L2): the chain gathers from the table of
@@ -461,7 +461,7 @@ def test_resampler_large_N_truncated_table(cs, oracle, kind, B, seed):
     bit-identical to the oracle's plain chain.  'adversarial' plants what the shortcut must not
     decide by itself: runs of equal weights (ratio exactly 1), ratios a hair from every u-independent
     boundary, zeros, denormals, huge values, negatives, NaN."""
-    N = 1_000_000 if B == 10 else 450_000
+    N = 1_000_000 if B == 10 else 131_072 if B == 100 else 450_000  # (B = 100, N = 131072: the kernel with the table's head in LDS)
     rng = np.random.default_rng(42 + B)
     if kind == "densities":
         w = np.exp(-0.5 * rng.chisquare(32, N)) * 1e-20
@@ -1215,9 +1215,10 @@ def test_multi_device_run_on_two_physical_gpus(cs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,B,ndev", [(1_000_000, 100, 3), (5003, 40, 4), (7, 1000, 3), (100_000, 1, 2)])
+@pytest.mark.parametrize("N,B,ndev", [(1_000_000, 100, 3), (300_000, 100, 3), (5003, 40, 4), (7, 1000, 3), (100_000, 1, 2)])
 def test_multi_device_resampler_equals_one_device(cs, oracle, N, B, ndev):
-    """cusmc_metropolis_multi_host (BASELINE configs[3] from the R boundary): the chains sharded
+    """(300 000 chains over three shards: each shard's 1e5 chains run the LDS-table kernel with a non-zero first chain.)
+    cusmc_metropolis_multi_host (BASELINE configs[3] from the R boundary): the chains sharded
     over a device list below the C ABI, one host thread and library-owned context per shard, every device given
     the whole weight vector; ancestors bitwise those of one device -- and of the oracle --, for the density and
     the log-weight chain, ragged and tiny shards included.  Rehearsed with every shard on device 0."""
@@ -1226,7 +1227,7 @@ def test_multi_device_resampler_equals_one_device(cs, oracle, N, B, ndev):
     one = cs.Sampler.metropolis_hastings(w, B=B, seed=77, t=3)
     many = cs.Sampler.metropolis_hastings(w, B=B, seed=77, t=3, devices=[0] * ndev)
     assert np.array_equal(one, many)
-    if N <= 100_000:
+    if N <= 300_000:
         assert np.array_equal(one, oracle.metropolis(w, B, 77, step=3))
     lw = np.log(w)
     assert np.array_equal(cs.Sampler.metropolis_hastings_log(lw, B=B, seed=78, t=2),
