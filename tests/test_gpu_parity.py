@@ -1190,6 +1190,9 @@ def test_multi_device_run_chunked_copy_out(cs, monkeypatch, chunk):
         assert np.array_equal(one[k], many[k]), k
     partial = cs.run(*args, seed=3, devices=[0, 0])
     assert np.array_equal(partial["posterior_x"], one["posterior_x"]) and np.array_equal(partial["weights"], one["weights"])
+    single = cs.run(*args, seed=3, return_ancestors=True, devices=[0])   # a one-entry list: that device's library-owned context
+    for k in ("ancestors", "posterior_x", "weights"):
+        assert np.array_equal(one[k], single[k]), k
 
 
 @pytest.mark.gpu
