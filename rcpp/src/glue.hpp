@@ -38,7 +38,7 @@ Session &session();
 // fresh std::random_device seed per call: src/samplers.cpp:10-11).  Every call gets a Philox key of
 // its own, cusmc_stream_key(seed, call counter): successive calls are independent replications and
 // never share counters, and CUSMC_SEED reproduces the whole sequence of calls of a session.
-uint64_t next_key();
+inline uint64_t next_key();
 
 // A distribution object of the reference's Distributions registry (src/mcmc.cpp:53-58) with the
 // host values it was built from; owned by the session's cache.
