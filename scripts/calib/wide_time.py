@@ -7,7 +7,7 @@ from scripts.logpdf_sweep import timed
 ctx = cusmc_amd.api.default_context().use_torch_stream()
 g = torch.Generator(device="cuda").manual_seed(7)
 rng = np.random.default_rng(0)
-for d in (192, 185, 208, 224, 240, 256):
+for d in [int(v) for v in os.environ.get("WIDE_TIME_DS", "192,185,208,224,240,256").split(",")]:
     N = int(1.28e8 // d)
     X = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
     out = torch.empty(N, dtype=torch.float64, device="cuda")
