@@ -204,6 +204,9 @@ hipError_t launch_logpdf_mfma(const double *X, int64_t N, int64_t ldx, int d, bo
 #if CUSMC_TILE_MAX_NB >= 11
     CUSMC_CASE(11)
 #endif
+#if CUSMC_TILE_MAX_NB >= 12
+    CUSMC_CASE(12)
+#endif
   }
 #undef CUSMC_CASE
 #undef CUSMC_EPI

@@ -1,6 +1,9 @@
 """Times the wide log-pdf kernel per block count (d = 16 NB, NB = 12 .. 16) for the library in place."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from cusmc_amd import _lib
+if os.environ.get("EXP"):  # (A/B against a calibration build: see scripts/d128_ab.py)
+    _lib.SO_PATH = _lib.SO_PATH.replace("libcusmc_hip.so", "libcusmc_hip_exp.so")
 import numpy as np, torch
 import cusmc_amd
 from scripts.logpdf_sweep import timed
