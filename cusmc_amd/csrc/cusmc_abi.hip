@@ -1002,33 +1002,35 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
     // device image: [frags(Q) | frags(G) | m0], fragments in the MFMA operand order; factors
     // zero-padded to 16*ceil(d/16)
     const int nb = (d + 15) / 16, dp = 16 * nb;
-    const size_t nf = (size_t)cusmc::mfma_num_frags(nb, false) * 64;
+    // a lower triangular Q (a Cholesky factor: what cusmc_pf_run_* passes) travels and multiplies as a triangle
+    const bool triq = nb >= 2 && cusmc::la::is_lower_triangular(Q, d);
+    const size_t nf = (size_t)cusmc::mfma_num_frags(nb, false) * 64, nfq = (size_t)cusmc::mfma_num_frags(nb, triq) * 64;
     // a diagonal G (random walk, AR(1) per component) under a dense Q needs no second matrix product:
     // its d entries travel instead of its fragments
     // (from d = 17 up: at one 16-block the 8-byte gathers cost more than the block's 16 MFMAs save,
     // 81 against 69 us per 1e6 particles)
     const bool g_diag = G && nb >= 2 && cusmc::la::is_diagonal(G, d);
-    if (int rc = image(g_diag ? 5 : 2, 2 * nf + d, [&](std::vector<double> &img) {
+    if (int rc = image((g_diag ? 5 : 2) + (triq ? 16 : 0), nfq + nf + d, [&](std::vector<double> &img) {
           std::vector<double> Mp;
-          auto pack = [&](const double *M, double *dst) {
-            if (dp == d) { cusmc::mfma_pack_frags(M, d, false, dst); return; }
+          auto pack = [&](const double *M, bool tri, double *dst) {
+            if (dp == d) { cusmc::mfma_pack_frags(M, d, tri, dst); return; }
             Mp.assign((size_t)dp * dp, 0.0);
             for (int i = 0; i < d; ++i) std::copy(M + (size_t)i * d, M + (size_t)(i + 1) * d, Mp.begin() + (size_t)i * dp);
-            cusmc::mfma_pack_frags(Mp.data(), dp, false, dst);
+            cusmc::mfma_pack_frags(Mp.data(), dp, tri, dst);
           };
-          pack(Q, img.data());
+          pack(Q, triq, img.data());
           if (g_diag) {
-            for (int j = 0; j < d; ++j) img[nf + j] = G[(size_t)j * d + j];
+            for (int j = 0; j < d; ++j) img[nfq + j] = G[(size_t)j * d + j];
           } else if (G) {
-            pack(G, img.data() + nf);
+            pack(G, false, img.data() + nfq);
           }
-          if (m0) std::copy(m0, m0 + d, img.begin() + 2 * nf);
+          if (m0) std::copy(m0, m0 + d, img.begin() + nfq + nf);
         }))
       return rc;
     const double *base = (const double *)ctx->draw_img.p;
-    HIP_TRY(cusmc::launch_propagate_mfma(kind, nu, X_prev_dev, a_dev, base, G ? base + nf : nullptr, g_diag,
-                                         m0 ? base + 2 * nf : nullptr, d, scale, seed, step, domain, first,
-                                         count, X_out_dev, ctx->num_cus, ctx->stream));
+    HIP_TRY((triq ? cusmc::launch_propagate_mfma_tri : cusmc::launch_propagate_mfma)(
+        kind, nu, X_prev_dev, a_dev, base, G ? base + nfq : nullptr, g_diag, m0 ? base + nfq + nf : nullptr, d, scale, seed,
+        step, domain, first, count, X_out_dev, ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
   // (CUSMC_PROPAGATE_ROWS=1 when the context was created: round 1's one-workgroup-per-particle kernel instead, for A/B timing)
@@ -1036,26 +1038,28 @@ int draws(cusmc_ctx *ctx, int kind, float nu, const double *X_prev_dev, const ui
     // 128 < d <= 256: matrix cores with the output blocks split over the waves (kernels/propagate_mfma_wide.hip).
     // device image: [frags(Q) | frags(G) or diag(G) or m0], factors zero-padded to 16*ceil(d/16)
     const int nb = (d + 15) / 16, dp = 16 * nb;
-    const size_t nf = (size_t)cusmc::mfma_num_frags(nb, false) * 64;
+    const bool triq = cusmc::la::is_lower_triangular(Q, d);
+    const size_t nf = (size_t)cusmc::mfma_num_frags(nb, false) * 64, nfq = (size_t)cusmc::mfma_num_frags(nb, triq) * 64;
     const bool g_diag = G && cusmc::la::is_diagonal(G, d);
     const int mode = !G ? 0 : g_diag ? 4 : 1;
-    if (int rc = image(mode == 1 ? 6 : mode == 4 ? 7 : 8, nf + (mode == 1 ? nf : (size_t)dp), [&](std::vector<double> &img) {
+    if (int rc = image((mode == 1 ? 6 : mode == 4 ? 7 : 8) + (triq ? 16 : 0), nfq + (mode == 1 ? nf : (size_t)dp), [&](std::vector<double> &img) {
           std::vector<double> Mp;
-          auto pack = [&](const double *M, double *dst) {
-            if (dp == d) { cusmc::mfma_pack_frags(M, d, false, dst); return; }
+          auto pack = [&](const double *M, bool tri, double *dst) {
+            if (dp == d) { cusmc::mfma_pack_frags(M, d, tri, dst); return; }
             Mp.assign((size_t)dp * dp, 0.0);
             for (int i = 0; i < d; ++i) std::copy(M + (size_t)i * d, M + (size_t)(i + 1) * d, Mp.begin() + (size_t)i * dp);
-            cusmc::mfma_pack_frags(Mp.data(), dp, false, dst);
+            cusmc::mfma_pack_frags(Mp.data(), dp, tri, dst);
           };
-          pack(Q, img.data());
-          if (mode == 1) pack(G, img.data() + nf);
-          else if (mode == 4) for (int j = 0; j < d; ++j) img[nf + j] = G[(size_t)j * d + j];
-          else if (m0) std::copy(m0, m0 + d, img.begin() + nf);
+          pack(Q, triq, img.data());
+          if (mode == 1) pack(G, false, img.data() + nfq);
+          else if (mode == 4) for (int j = 0; j < d; ++j) img[nfq + j] = G[(size_t)j * d + j];
+          else if (m0) std::copy(m0, m0 + d, img.begin() + nfq);
         }))
       return rc;
     const double *base = (const double *)ctx->draw_img.p;
-    HIP_TRY(cusmc::launch_propagate_mfma_wide(kind, nu, X_prev_dev, a_dev, base, base + nf, mode, d, scale, seed, step, domain,
-                                              first, count, X_out_dev, ctx->num_cus, ctx->stream));
+    HIP_TRY((triq ? cusmc::launch_propagate_mfma_wide_tri : cusmc::launch_propagate_mfma_wide)(
+        kind, nu, X_prev_dev, a_dev, base, base + nfq, mode, d, scale, seed, step, domain, first, count, X_out_dev,
+        ctx->num_cus, ctx->stream));
     return CUSMC_OK;
   }
   if (d > 128) {
@@ -1385,6 +1389,30 @@ namespace {
 // launches only: for a small filter the per-step uploads (two 16..2048-byte copies in the stream) would cost
 // more than the launches.  Same values as the per-step plan, bit for bit.  Installs the plan for y_1 (and, for
 // the fused step, the [Q | G] image); `host` must stay alive until the upload has run.
+// The filter's square roots of C0 and W.  Default: eigenSolver's V sqrt(Lambda), as MCMC() computes them
+// (src/mcmc.cpp:70-71, 280; src/linear_algebra.cpp:10-23).  CUSMC_PROPOSAL_FACTOR=cholesky: the lower Cholesky factor
+// instead where the matrix is positive definite -- the same law (Q Q^T is what the proposal's covariance is), other
+// realisations, and from d = 32 up the proposal's Q xi costs half the matrix-core work (kernels/propagate_mfma*.hip:
+// TRIQ); a matrix that is only semi-definite keeps the eigen form.
+int filter_factors(const double *C0, const double *W, int d, std::vector<double> &Q0, std::vector<double> &Qw)
+{
+  bool chol = false;
+  if (const char *env = getenv("CUSMC_PROPOSAL_FACTOR")) {
+    if (!strcmp(env, "cholesky")) chol = true;
+    else if (strcmp(env, "eigen") != 0)
+      return fail(CUSMC_EINVAL, "CUSMC_PROPOSAL_FACTOR=\"%s\": expected \"eigen\" or \"cholesky\"", env);
+  }
+  auto root = [&](const double *S, std::vector<double> &Q) {
+    Q.assign((size_t)d * d, 0.0);
+    std::vector<double> L;
+    if (chol && cusmc::la::cholesky(S, d, L) == 0) Q = L;
+    else cusmc::la::eigen_sqrt(S, d, Q.data());
+  };
+  root(C0, Q0);
+  root(W, Qw);
+  return CUSMC_OK;
+}
+
 struct ObsTable {
   std::vector<double> host;
   DevBuf dev;
@@ -1449,9 +1477,8 @@ int pf_run_single(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T
     fprintf(stderr, "[cusmc_pf_run_host] %-28s %8.2f ms\n", name, (t - t_prev) * 1e3);
     t_prev = t;
   };
-  std::vector<double> Q0((size_t)d * d), Qw((size_t)d * d);
-  cusmc::la::eigen_sqrt(C0, d, Q0.data());
-  cusmc::la::eigen_sqrt(W, d, Qw.data());
+  std::vector<double> Q0, Qw;
+  if (int rc = filter_factors(C0, W, d, Q0, Qw)) return rc;
 
   cusmc_dist *obs = nullptr;  // pdf_{0,V}: reweight_G sets mu = 0, sigma = V (mcmc.cpp:188-189)
   if (int rc = cusmc_dist_create(ctx, kind, nullptr, V, d, df, &obs)) return rc;
@@ -1756,9 +1783,8 @@ CUSMC_EXPORT int cusmc_pf_run_multi_host(const int *devices, int ndev, const dou
       (void)hipGetLastError();
     }
 
-  std::vector<double> Q0((size_t)d * d), Qw((size_t)d * d);
-  cusmc::la::eigen_sqrt(C0, d, Q0.data());
-  cusmc::la::eigen_sqrt(W, d, Qw.data());
+  std::vector<double> Q0, Qw;
+  if (int rc = filter_factors(C0, W, d, Q0, Qw)) return rc;
 
   std::vector<FilterShard> sh(ndev);
   for (int r = 0; r < ndev; ++r) {

@@ -20,7 +20,17 @@
 // serialised: the Philox blocks and Box-Muller pairs (8 per lane per tile at d = 64; ln and
 // sincos(2 pi u) from smallops.h) weigh as much as the 128 MFMAs -- it is RNG-bound, not HBM-bound.  Workgroup = 8 waves sharing the LDS factor image and
 // an LDS tile counter.
+//
+// TRIQ: Q is LOWER TRIANGULAR (a Cholesky factor: what cusmc_pf_run_* hands down, and what a caller's Q is
+// recognised as when its upper part is zero).  Q Xi then needs the k-blocks kb <= cb only -- 4 NB (NB + 1) / 2
+// block-products instead of 4 NB^2, the fragments packed triangular as for the log-density kernels
+// (mfma_pack_frags, tri = true).  The triangular instantiations are a translation unit of their own
+// (propagate_mfma_tri.hip: this file with CUSMC_TRIQ = 1).
 #include "smallops.h"
+
+#ifndef CUSMC_TRIQ
+#define CUSMC_TRIQ 0
+#endif
 
 namespace cusmc {
 
@@ -29,6 +39,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));  // rows are 8-byte aligned in general
 
 __host__ __device__ constexpr int pm_pi(int s, int h) { return 2 * h + (s & 1) + 8 * (s >> 1); }
+__host__ __device__ constexpr int pm_q_frags(int nb, bool triq) { return triq ? 2 * nb * (nb + 1) : 4 * nb * nb; }
 
 static __device__ __forceinline__ void pm_normal_pair(const u32x4 r, double &z0, double &z1)
 {
@@ -38,10 +49,12 @@ static __device__ __forceinline__ void pm_normal_pair(const u32x4 r, double &z0,
 // Every 16 <= d <= 128 and any 8-byte aligned batch.  d <= 96 keeps both factors in LDS (one
 // launch); 96 < d <= 128 runs two launches, one factor each (131 KB at d = 128): first
 // x = [diag(c)] Q xi, then x += G x_prev[a].
+#if !CUSMC_TRIQ
 bool propagate_mfma_supported(int d, const void *X_prev, const void *X_out)
 {
   return d >= 16 && d <= 128 && (uintptr_t)X_prev % 8 == 0 && (uintptr_t)X_out % 8 == 0;
 }
+#endif
 
 // MODE 0: initial / R-level draw     x = [diag(c)] Q xi + m0
 //      1: propagate, one launch      x = [diag(c)] Q xi + G x_prev[a]
@@ -53,7 +66,7 @@ bool propagate_mfma_supported(int d, const void *X_prev, const void *X_out)
 // PAD: d is not 16*NB (factors zero-padded on the host) or rows are not 16-byte aligned: the last
 // k-block of the gathered row is loaded element by element, column clamped into the row, columns
 // >= d zeroed; normals for pairs past d are not drawn; outputs past d are not stored.
-template <int NB, bool MVT, int MODE, bool PAD>
+template <int NB, bool MVT, int MODE, bool PAD, bool TRIQ>
 __global__ __launch_bounds__(512) void propagate_mfma_kernel(
     float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
     const double *__restrict__ fragsQ, const double *__restrict__ fragsG, const double *__restrict__ m0,
@@ -61,18 +74,18 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
     uint32_t count, double *__restrict__ X_out, long num_tiles)
 {
   constexpr int D = 16 * NB;
-  constexpr int NFRAG = 4 * NB * NB;
+  constexpr int NFRAG = 4 * NB * NB, NFRAGQ = pm_q_frags(NB, TRIQ);
   constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0, DIAG_G = MODE == 4;
   constexpr bool SPLIT_ACC = (MVT && HAS_Q && HAS_G) || HAS_M0 || MODE == 3;  // accG separate from accQ
   extern __shared__ double lds[];
-  double *sQ = lds;                                  // NFRAG x 64 (HAS_Q)
-  double *sG = sQ + (HAS_Q ? NFRAG * 64 : 0);        // NFRAG x 64 (HAS_G), or m0 / diag(G) padded to D
+  double *sQ = lds;                                  // NFRAGQ x 64 (HAS_Q)
+  double *sG = sQ + (HAS_Q ? NFRAGQ * 64 : 0);       // NFRAG x 64 (HAS_G), or m0 / diag(G) padded to D
   int *sNext = reinterpret_cast<int *>(sG + (HAS_G ? NFRAG * 64 : (HAS_M0 || DIAG_G ? D : 0)));
 
-  for (int i = threadIdx.x; i < NFRAG * 32; i += 512) {
-    if (HAS_Q) reinterpret_cast<v2d *>(sQ)[i] = reinterpret_cast<const v2d *>(fragsQ)[i];
-    if (HAS_G) reinterpret_cast<v2d *>(sG)[i] = reinterpret_cast<const v2d *>(fragsG)[i];
-  }
+  if (HAS_Q)
+    for (int i = threadIdx.x; i < NFRAGQ * 32; i += 512) reinterpret_cast<v2d *>(sQ)[i] = reinterpret_cast<const v2d *>(fragsQ)[i];
+  if (HAS_G)
+    for (int i = threadIdx.x; i < NFRAG * 32; i += 512) reinterpret_cast<v2d *>(sG)[i] = reinterpret_cast<const v2d *>(fragsG)[i];
   if (HAS_M0 && threadIdx.x < D) sG[threadIdx.x] = (int)threadIdx.x < d ? m0[threadIdx.x] : 0.0;
   if (DIAG_G && threadIdx.x < D) sG[threadIdx.x] = (int)threadIdx.x < d ? fragsG[threadIdx.x] : 0.0;
   if (threadIdx.x == 0) *sNext = 0;
@@ -158,14 +171,17 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
         accG[cb] = v4d{0.0, 0.0, 0.0, 0.0};
       }
     }
-    int f = 0;
+    int f = 0, fq = 0;  // (compile-time after unrolling; TRIQ: the Q image holds the blocks cb >= kb only)
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb, ++f) {
-          if (HAS_Q) accQ[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sQ[f * 64 + lds_lane], xi[kb][s], accQ[cb], 0, 0, 0);
+          if (HAS_Q && (!TRIQ || cb >= kb)) {
+            accQ[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sQ[fq * 64 + lds_lane], xi[kb][s], accQ[cb], 0, 0, 0);
+            ++fq;
+          }
           if (HAS_G) {
             v4d &dst = SPLIT_ACC ? accG[cb] : accQ[cb];  // mvn, one launch: one accumulator takes both products
             dst = __builtin_amdgcn_mfma_f64_16x16x4f64(sG[f * 64 + lds_lane], xg[kb][s >> 1][s & 1], dst, 0, 0, 0);
@@ -206,17 +222,17 @@ __global__ __launch_bounds__(512) void propagate_mfma_kernel(
   }
 }
 
-template <int NB, bool MVT, int MODE, bool PAD>
+template <int NB, bool MVT, int MODE, bool PAD, bool TRIQ>
 static hipError_t launch_pm(float nu, const double *X_prev, const uint32_t *a, const double *fragsQ,
                             const double *fragsG, const double *m0, int d, double scale, uint64_t seed,
                             uint32_t step, uint32_t domain, uint32_t first, uint32_t count, double *X_out,
                             int num_cus, hipStream_t stream)
 {
-  constexpr int NFRAG = 4 * NB * NB;
+  constexpr int NFRAG = 4 * NB * NB, NFRAGQ = pm_q_frags(NB, TRIQ);
   constexpr bool HAS_Q = MODE != 3, HAS_G = MODE == 1 || MODE == 3, HAS_M0 = MODE == 0, DIAG_G = MODE == 4;
-  const size_t lds_bytes = (size_t)((HAS_Q ? NFRAG * 64 : 0) + (HAS_G ? NFRAG * 64 : (HAS_M0 || DIAG_G ? 16 * NB : 0)) + 2) * sizeof(double) +
+  const size_t lds_bytes = (size_t)((HAS_Q ? NFRAGQ * 64 : 0) + (HAS_G ? NFRAG * 64 : (HAS_M0 || DIAG_G ? 16 * NB : 0)) + 2) * sizeof(double) +
                            ((MVT && HAS_Q) ? 8 * sizeof(ChiQueue) : 0);
-  auto kern = propagate_mfma_kernel<NB, MVT, MODE, PAD>;
+  auto kern = propagate_mfma_kernel<NB, MVT, MODE, PAD, TRIQ>;
   static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
   const long num_tiles = ((long)count + 15) / 16;
@@ -229,7 +245,13 @@ static hipError_t launch_pm(float nu, const double *X_prev, const uint32_t *a, c
 
 // fragsQ / fragsG: mfma_pack_frags of the factors zero-padded to 16*ceil(d/16) (fragsG == NULL: the
 // initial draw, + m0).  g_is_diagonal: fragsG holds the d diagonal entries of G instead.
-hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const uint32_t *a,
+// launch_propagate_mfma_tri: Q lower triangular, fragsQ packed with tri = true (G dense as before).
+#if CUSMC_TRIQ
+#define CUSMC_PM_ENTRY launch_propagate_mfma_tri
+#else
+#define CUSMC_PM_ENTRY launch_propagate_mfma
+#endif
+hipError_t CUSMC_PM_ENTRY(int kind, float nu, const double *X_prev, const uint32_t *a,
                                  const double *fragsQ, const double *fragsG, bool g_is_diagonal, const double *m0, int d,
                                  double scale, uint64_t seed, uint32_t step, uint32_t domain,
                                  uint32_t first, uint32_t count, double *X_out, int num_cus,
@@ -238,10 +260,11 @@ hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const
   if (count == 0) return hipSuccess;
   const bool mvt = kind == CUSMC_MVT, gather = fragsG != nullptr;
   const bool pad = d % 16 != 0 || (gather && !g_is_diagonal && (uintptr_t)X_prev % 16 != 0);
+  constexpr bool TQ = CUSMC_TRIQ != 0;
 #define CUSMC_ARGS nu, X_prev, a, fragsQ, fragsG, m0, d, scale, seed, step, domain, first, count, X_out, num_cus, stream
 #define CUSMC_PMV(nb, mode)                                                                                  \
-  (mvt ? (pad ? launch_pm<nb, true, mode, true>(CUSMC_ARGS) : launch_pm<nb, true, mode, false>(CUSMC_ARGS))  \
-       : (pad ? launch_pm<nb, false, mode, true>(CUSMC_ARGS) : launch_pm<nb, false, mode, false>(CUSMC_ARGS)))
+  (mvt ? (pad ? launch_pm<nb, true, mode, true, TQ>(CUSMC_ARGS) : launch_pm<nb, true, mode, false, TQ>(CUSMC_ARGS))  \
+       : (pad ? launch_pm<nb, false, mode, true, TQ>(CUSMC_ARGS) : launch_pm<nb, false, mode, false, TQ>(CUSMC_ARGS)))
 #define CUSMC_PM1(nb) /* both factors fit the LDS */ \
   case nb: return !gather ? CUSMC_PMV(nb, 0) : g_is_diagonal ? CUSMC_PMV(nb, 4) : CUSMC_PMV(nb, 1);
 #define CUSMC_PM2(nb) /* one factor per launch */                                   \
@@ -251,10 +274,16 @@ hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const
     const hipError_t e = CUSMC_PMV(nb, 2);                                          \
     return e != hipSuccess ? e : CUSMC_PMV(nb, 3);                                  \
   }
+#if CUSMC_TRIQ
+  // d = 97 .. 112 with a triangular Q: 56 KB + 98 KB fit the LDS together (the Student-t form's queues do not)
+  if ((d + 15) / 16 == 7 && gather && !g_is_diagonal && !mvt)
+    return pad ? launch_pm<7, false, 1, true, true>(CUSMC_ARGS) : launch_pm<7, false, 1, false, true>(CUSMC_ARGS);
+#endif
   switch ((d + 15) / 16) {
     CUSMC_PM1(1) CUSMC_PM1(2) CUSMC_PM1(3) CUSMC_PM1(4) CUSMC_PM1(5) CUSMC_PM1(6)
     CUSMC_PM2(7) CUSMC_PM2(8)
   }
+#undef CUSMC_PM_ENTRY
 #undef CUSMC_PM1
 #undef CUSMC_PM2
 #undef CUSMC_PMV

@@ -14,7 +14,7 @@
 //             sub = 8 kb + 4 h2 + h: the RNG contract keys a block by component pair), resp. one 16-byte piece of
 //             the ancestor's row.  Wave w fills tile w % 4, half w / 4 of every k-block; a lane writes its 16
 //             bytes at slab + 16 lane; a compute wave reads a slab back with one conflict-free ds_read_b128.
-//   multiply  wave w owns output blocks w and w + 8 for the four tiles; the A fragments of its blocks stream
+//   multiply  wave w owns output blocks w and NB - 1 - w (one block where that is not above w) for the four tiles; the A fragments of its blocks stream
 //             from L2 (mfma_pack_frags order, 512 contiguous bytes per fragment, buffer loads) one k-block ahead
 //             of their use, each feeding FOUR MFMAs: 2 blocks x 4 tiles x 4 NB MFMAs per factor, group and wave.
 //   the two products take TURNS on one set of slabs (128 KB at d = 256): normals -> Q Xi -> [Student-t: scale] ->
@@ -33,9 +33,18 @@
 //
 // d that is not a multiple of 16 runs with the factors zero-padded to 16 NB on the host (PAD): normals
 // for pairs past d are not drawn, gathered columns past d are zeroed, outputs past d are not stored.
+//
+// TRIQ (propagate_mfma_wide_tri.hip: this file with CUSMC_TRIQ = 1): Q is LOWER TRIANGULAR (a Cholesky factor), its
+// fragments packed triangular (mfma_pack_frags, tri = true).  Output block cb of Q Xi needs the k-blocks kb <= cb only;
+// the pair (w, NB - 1 - w) costs NB + 1 block-products on every wave -- 136 per tile at d = 256 instead of 256 -- in
+// two phases: both blocks up to kb = w, then the upper one alone.  G x stays dense.
 #include <type_traits>
 
 #include "smallops.h"
+
+#ifndef CUSMC_TRIQ
+#define CUSMC_TRIQ 0
+#endif
 
 namespace cusmc {
 
@@ -46,13 +55,15 @@ typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));  // rows 
 constexpr int kWideTiles = 4;          // 16-particle tiles per group
 constexpr int kWideGroup = 16 * kWideTiles;
 
+#if !CUSMC_TRIQ
 bool propagate_mfma_wide_supported(int d, const void *X_prev, const void *X_out)
 {
   return d > 128 && d <= 256 && (uintptr_t)X_prev % 8 == 0 && (uintptr_t)X_out % 8 == 0;
 }
+#endif
 
 // one set of slabs (the two products take turns); the Student-t kernel also parks 8 waves x 16 KB of accumulators there
-size_t propagate_wide_lds_bytes(int nb, bool mvt)
+static size_t propagate_wide_lds_bytes(int nb, bool mvt)
 {
   const size_t slabs = (size_t)nb * 2 * kWideTiles * 1024, park = 8 * 16384;
   return (mvt && park > slabs ? park : slabs) + (mvt ? 8 * sizeof(ChiQueue) : 0);  // (+ a queue per wave for its open chi^2 draws)
@@ -75,7 +86,7 @@ __device__ unsigned long long g_pw_phases[8 * 1024];
 #define PW_STAMP(k) do { } while (0)
 #endif
 
-template <int NB, bool MVT, int MODE, bool PAD>
+template <int NB, bool MVT, int MODE, bool PAD, bool TRIQ>
 __global__ __launch_bounds__(512) void propagate_wide_kernel(
     float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
     const double *__restrict__ fragsQ, const double *__restrict__ tail, int d, double scale, uint32_t k0,
@@ -96,9 +107,10 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
   if (MVT && lane == 0) chi_q->count = 0;  // (the first use lies behind several __syncthreads())
   const int p = lane & 15, h = lane >> 4;
   const ChiSquare cs = chi_setup(MVT ? nu : 2.0f);
-  // this wave's output blocks: w, and w + 8 if there is one
-  const int cb0 = w, cb1 = w + 8;
-  const bool two = cb1 < NB;
+  // this wave's output blocks: w, and NB - 1 - w for the NB - 8 waves that carry two (with a triangular Q a pair costs
+  // (w + 1) + (NB - w) k-blocks whatever w is)
+  const int cb0 = w, cb1 = NB - 1 - w;
+  const bool two = w < NB - 8;
   // this wave's share of a fill: slabs w + 8 kb, kb = 0 .. NB - 1 -- tile ft, half fh2 of every k-block
   const int ft = w & 3, fh2 = w >> 2;
 
@@ -166,24 +178,33 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
     // branch around every second MFMA and every second fragment load, and hipcc's waitcnt pass, which must serve the
     // path with the fewest loads in flight, then waited for the fragments of k-block kb + 1 before the MFMAs of
     // k-block kb (vmcnt(7) .. vmcnt(0) with eight loads just issued): the prefetch distance was zero.
-    auto product = [&](auto two_tag, const double *__restrict__ frags) {
+    // `tri_tag`: the fragment image holds the blocks cb >= kb only (mfma_pack_frags, tri = true); `member_tag`: which of
+    // the wave's two blocks a one-block product works on; k-blocks [kb_begin, kb_end).
+    auto product = [&](auto two_tag, auto member_tag, auto tri_tag, const double *__restrict__ frags, int kb_begin, int kb_end) {
       constexpr bool TWO = decltype(two_tag)::value;
-      // fragment (kb, s, cb) is at ((kb 4 + s) NB + cb) x 64.  Both operands of k-block kb + 1 -- eight fragment
-      // values from L2, eight 16-byte pieces from LDS -- are requested before the MFMAs of k-block kb are issued;
-      // two register sets swap roles (loop unrolled by two: no copies).
+      constexpr int MB = decltype(member_tag)::value;
+      constexpr bool TRI = decltype(tri_tag)::value;
+      if (kb_begin >= kb_end) return;
+      // dense: fragment (kb, s, cb) is at ((kb 4 + s) NB + cb) x 64; triangular: k-block kb starts behind the
+      // 4 (NB + NB - 1 + .. + NB - kb + 1) fragments of the earlier ones and holds 4 x (NB - kb).  Both operands of
+      // k-block kb + 1 -- eight fragment values from L2, eight 16-byte pieces from LDS -- are requested before the
+      // MFMAs of k-block kb are issued; two register sets swap roles (loop unrolled by two: no copies).
       double wa[4][2], wb[4][2];
       v2d xa[2][T], xb[2][T];
-      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(frags), 0, NB * 4 * NB * 512, 0x00020000);
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(frags), 0,
+                                                          (TRI ? 2 * NB * (NB + 1) : NB * 4 * NB) * 512, 0x00020000);
       const int lane8 = lane * 8;
+      const int cbs = MB ? cb1 : cb0;  // the block of a one-block product
       auto load_w = [&](int kb, double(&dst)[4][2]) {
+        const int kbase = TRI ? 4 * (kb * NB - kb * (kb - 1) / 2) - kb : 0, width = TRI ? NB - kb : NB;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           // (buffer loads: SGPR descriptor + scalar fragment offset + one shared lane offset, instead of a 64-bit
           // VGPR pointer per fragment -- a dozen such pointers were the difference between 256 VGPRs with spills
           // and none)
-          const int off = ((kb * 4 + s) * NB + cb0) * 512;
-          dst[s][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, off, 0));
-          if constexpr (TWO) dst[s][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, off + 8 * 512, 0));
+          const int row = TRI ? kbase + s * width : (kb * 4 + s) * NB;
+          dst[s][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, (row + (TWO ? cb0 : cbs)) * 512, 0));
+          if constexpr (TWO) dst[s][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, (row + cb1) * 512, 0));
         }
       };
       auto load_x = [&](int kb, v2d(&dst)[2][T]) {
@@ -198,19 +219,23 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             const double bv = xc[s >> 1][t][s & 1];
-            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][0], bv, acc[0][t], 0, 0, 0);
-            if constexpr (TWO) acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][1], bv, acc[1][t], 0, 0, 0);
+            if constexpr (TWO) {
+              acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][0], bv, acc[0][t], 0, 0, 0);
+              acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][1], bv, acc[1][t], 0, 0, 0);
+            } else {
+              acc[MB][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s][0], bv, acc[MB][t], 0, 0, 0);
+            }
           }
       };
       // The loop body requests UNCONDITIONALLY (the last one or two k-blocks are peeled off behind it): a branch
       // around a request leaves the waitcnt pass two paths to serve, and it serves the one without the new loads --
       // vmcnt(7) .. vmcnt(0) in front of MFMAs whose operands arrived a k-block ago, i.e. a wait for the loads
       // just issued on every second k-block.
-      load_w(0, wa);
-      load_x(0, xa);
-      int kb = 0;
+      load_w(kb_begin, wa);
+      load_x(kb_begin, xa);
+      int kb = kb_begin;
 #pragma unroll 1
-      for (; kb + 2 < NB; kb += 2) {
+      for (; kb + 2 < kb_end; kb += 2) {
         load_w(kb + 1, wb);
         load_x(kb + 1, xb);
         mfmas(wa, xa);
@@ -218,24 +243,35 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
         load_x(kb + 2, xa);
         mfmas(wb, xb);
       }
-      if constexpr (NB % 2 == 0) {
-        load_w(NB - 1, wb);
-        load_x(NB - 1, xb);
+      if (kb + 2 == kb_end) {
+        load_w(kb + 1, wb);
+        load_x(kb + 1, xb);
         mfmas(wa, xa);
         mfmas(wb, xb);
       } else {
         mfmas(wa, xa);
       }
     };
-    auto multiply = [&](const double *__restrict__ frags) {
-      if constexpr (NB == 16) {
-        product(std::true_type{}, frags);
+    using Two = std::true_type;
+    using One = std::false_type;
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    auto multiply_dense = [&](const double *__restrict__ frags) {
+      if (NB == 16 || two) product(Two{}, M0{}, std::false_type{}, frags, 0, NB);
+      else product(One{}, M0{}, std::false_type{}, frags, 0, NB);
+    };
+    // triangular: both blocks up to k-block cb0, then the upper block alone up to cb1; a one-block wave up to cb0
+    auto multiply_tri = [&](const double *__restrict__ frags) {
+      if (NB == 16 || two) {
+        product(Two{}, M0{}, std::true_type{}, frags, 0, cb0 + 1);
+        product(One{}, M1{}, std::true_type{}, frags, cb0 + 1, cb1 + 1);
       } else {
-        if (two) product(std::true_type{}, frags);
-        else product(std::false_type{}, frags);
+        product(One{}, M0{}, std::true_type{}, frags, 0, cb0 + 1);
       }
     };
-    multiply(fragsQ);
+    auto multiply = [&](const double *__restrict__ frags) { multiply_dense(frags); };
+    if constexpr (TRIQ) multiply_tri(fragsQ);
+    else multiply_dense(fragsQ);
     PW_STAMP(3);
     // lane (p, h), register r of block b holds output dim j = 16 cb_b + h + 4 r of particle p
     if constexpr (MVT) {
@@ -317,13 +353,13 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
   }
 }
 
-template <int NB, bool MVT, int MODE, bool PAD>
+template <int NB, bool MVT, int MODE, bool PAD, bool TRIQ>
 static hipError_t launch_pw(float nu, const double *X_prev, const uint32_t *a, const double *fragsQ, const double *tail,
                             int d, double scale, uint64_t seed, uint32_t step, uint32_t domain, uint32_t first,
                             uint32_t count, double *X_out, int num_cus, hipStream_t stream)
 {
   const size_t lds_bytes = propagate_wide_lds_bytes(NB, MVT);
-  auto kern = propagate_wide_kernel<NB, MVT, MODE, PAD>;
+  auto kern = propagate_wide_kernel<NB, MVT, MODE, PAD, TRIQ>;
   static LdsConfig lds_configured;
   if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_configured); e != hipSuccess) return e;
   const long num_groups = ((long)count + kWideGroup - 1) / kWideGroup;
@@ -334,9 +370,15 @@ static hipError_t launch_pw(float nu, const double *X_prev, const uint32_t *a, c
   return hipGetLastError();
 }
 
-// fragsQ: dense mfma_pack_frags image of Q zero-padded to 16 NB; tail: the same of G (mode 1), diag(G)
-// (mode 4) or m0 (mode 0), both padded to 16 NB entries where they are vectors.
-hipError_t launch_propagate_mfma_wide(int kind, float nu, const double *X_prev, const uint32_t *a, const double *fragsQ,
+// fragsQ: dense mfma_pack_frags image of Q zero-padded to 16 NB (launch_propagate_mfma_wide_tri: Q lower triangular,
+// packed with tri = true); tail: the dense image of G (mode 1), diag(G) (mode 4) or m0 (mode 0), both padded to 16 NB
+// entries where they are vectors.
+#if CUSMC_TRIQ
+#define CUSMC_PW_ENTRY launch_propagate_mfma_wide_tri
+#else
+#define CUSMC_PW_ENTRY launch_propagate_mfma_wide
+#endif
+hipError_t CUSMC_PW_ENTRY(int kind, float nu, const double *X_prev, const uint32_t *a, const double *fragsQ,
                                       const double *tail, int mode, int d, double scale, uint64_t seed, uint32_t step,
                                       uint32_t domain, uint32_t first, uint32_t count, double *X_out, int num_cus,
                                       hipStream_t stream)
@@ -344,11 +386,12 @@ hipError_t launch_propagate_mfma_wide(int kind, float nu, const double *X_prev, 
   if (count == 0) return hipSuccess;
   const bool mvt = kind == CUSMC_MVT;
   const bool pad = d % 16 != 0;
+  constexpr bool TQ = CUSMC_TRIQ != 0;
 #define CUSMC_PW_MODE(nb, m)                                                                                              \
-  (mvt ? (pad ? launch_pw<nb, true, m, true>(nu, X_prev, a, fragsQ, tail, d, scale, seed, step, domain, first, count, X_out, num_cus, stream)   \
-              : launch_pw<nb, true, m, false>(nu, X_prev, a, fragsQ, tail, d, scale, seed, step, domain, first, count, X_out, num_cus, stream)) \
-       : (pad ? launch_pw<nb, false, m, true>(nu, X_prev, a, fragsQ, tail, d, scale, seed, step, domain, first, count, X_out, num_cus, stream)  \
-              : launch_pw<nb, false, m, false>(nu, X_prev, a, fragsQ, tail, d, scale, seed, step, domain, first, count, X_out, num_cus, stream)))
+  (mvt ? (pad ? launch_pw<nb, true, m, true, TQ>(nu, X_prev, a, fragsQ, tail, d, scale, seed, step, domain, first, count, X_out, num_cus, stream)   \
+              : launch_pw<nb, true, m, false, TQ>(nu, X_prev, a, fragsQ, tail, d, scale, seed, step, domain, first, count, X_out, num_cus, stream)) \
+       : (pad ? launch_pw<nb, false, m, true, TQ>(nu, X_prev, a, fragsQ, tail, d, scale, seed, step, domain, first, count, X_out, num_cus, stream)  \
+              : launch_pw<nb, false, m, false, TQ>(nu, X_prev, a, fragsQ, tail, d, scale, seed, step, domain, first, count, X_out, num_cus, stream)))
 #define CUSMC_PW_CASE(nb) \
   case nb:                \
     return mode == 0 ? CUSMC_PW_MODE(nb, 0) : mode == 1 ? CUSMC_PW_MODE(nb, 1) : CUSMC_PW_MODE(nb, 4);
@@ -364,6 +407,7 @@ hipError_t launch_propagate_mfma_wide(int kind, float nu, const double *X_prev, 
   }
 #undef CUSMC_PW_CASE
 #undef CUSMC_PW_MODE
+#undef CUSMC_PW_ENTRY
   return hipErrorInvalidValue;
 }
 

@@ -132,6 +132,12 @@ hipError_t launch_propagate_mfma(int kind, float nu, const double *X_prev, const
                                  int d, double scale, uint64_t seed, uint32_t step, uint32_t domain,
                                  uint32_t first, uint32_t count, double *X_out, int num_cus,
                                  hipStream_t stream);
+// the same with a LOWER TRIANGULAR Q, fragsQ packed with tri = true (kernels/propagate_mfma_tri.hip)
+hipError_t launch_propagate_mfma_tri(int kind, float nu, const double *X_prev, const uint32_t *a,
+                                     const double *fragsQ, const double *fragsG, bool g_is_diagonal, const double *m0,
+                                     int d, double scale, uint64_t seed, uint32_t step, uint32_t domain,
+                                     uint32_t first, uint32_t count, double *X_out, int num_cus,
+                                     hipStream_t stream);
 
 // --- kernels/propagate_mfma_wide.hip : 128 < d <= 256, output blocks split over the waves -----------------
 // fragsQ: dense mfma_pack_frags image of Q (zero-padded to 16*ceil(d/16)); tail: the same of G (mode 1),
@@ -141,6 +147,11 @@ hipError_t launch_propagate_mfma_wide(int kind, float nu, const double *X_prev, 
                                       const double *tail, int mode, int d, double scale, uint64_t seed, uint32_t step,
                                       uint32_t domain, uint32_t first, uint32_t count, double *X_out, int num_cus,
                                       hipStream_t stream);
+// the same with a LOWER TRIANGULAR Q, fragsQ packed with tri = true (kernels/propagate_mfma_wide_tri.hip)
+hipError_t launch_propagate_mfma_wide_tri(int kind, float nu, const double *X_prev, const uint32_t *a, const double *fragsQ,
+                                          const double *tail, int mode, int d, double scale, uint64_t seed, uint32_t step,
+                                          uint32_t domain, uint32_t first, uint32_t count, double *X_out, int num_cus,
+                                          hipStream_t stream);
 
 // diagonal G (or none: m0) and diagonal Q, any d: one lane per component pair
 hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const uint32_t *a,

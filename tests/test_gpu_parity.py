@@ -632,6 +632,44 @@ def test_propagate_matches_oracle(cs, oracle, d, dist, nu):
     assert torch.equal(part, out[first:first + count])
 
 
+@pytest.mark.parametrize("d", [16, 17, 31, 32, 48, 64, 65, 96, 100, 112, 113, 128, 129, 144, 150, 177, 192, 201, 208, 224, 240, 255, 256])
+@pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0), ("mvt", 3.0)])
+def test_propagate_with_a_triangular_factor(cs, oracle, d, dist, nu):
+    """A LOWER TRIANGULAR Q (the Cholesky factor cusmc_pf_run_* passes down; recognised by its zero upper part)
+    takes the kernels' triangular instantiations -- Q xi over the k-blocks kb <= cb only, 97 <= d <= 112 in one
+    launch for the Normal proposal: against the oracle's dense loops on the same Q, with a dense G, a diagonal G
+    and for initialize() (m0 instead of G), shards composing as for the dense kernels."""
+    import torch
+    rng = np.random.default_rng(d + 1700)
+    N = 1000 + 7
+    Xp = rng.standard_normal((N, d))
+    a = rng.integers(0, N, N).astype(np.uint32)
+    Q = np.linalg.cholesky(0.2 * spd(rng, d))
+    assert np.all(np.triu(Q, 1) == 0.0)
+    ctx = cs.api.default_context().use_torch_stream()
+    Xd = torch.from_numpy(Xp).cuda()
+    ad = torch.from_numpy(a.astype(np.int32)).cuda()
+    for G in (0.9 * np.eye(d) + 0.3 * rng.standard_normal((d, d)) / np.sqrt(d), np.diag(0.5 + rng.random(d))):
+        want = oracle.propagate(Xp, a, G, Q, dist, nu, 1.0, seed=177, step=5)
+        out = torch.full((N + 1, d), float("nan"), dtype=torch.float64, device="cuda")
+        cs.api.propagate_dev(Xd, ad, G, Q, out[:N], dist, nu, 1.0, seed=177, step=5, ctx=ctx)
+        torch.cuda.synchronize()
+        assert np.allclose(out[:N].cpu().numpy(), want, rtol=1e-9, atol=1e-9)
+        assert bool(torch.isnan(out[N]).all())
+        first, count = 333, 401
+        part = torch.empty(count, d, dtype=torch.float64, device="cuda")
+        cs.api.propagate_dev(Xd, ad[first:first + count].contiguous(), G, Q, part, dist, nu, 1.0, seed=177, step=5,
+                             first=first, ctx=ctx)
+        torch.cuda.synchronize()
+        assert torch.equal(part, out[first:first + count])
+    m0 = rng.standard_normal(d)
+    want0, _ = oracle.initialize(N, m0, Q, dist, nu, 1.0, seed=177, step=0)
+    init = torch.empty(N, d, dtype=torch.float64, device="cuda")
+    cs.api.initialize_dev(m0, Q, init, dist, nu, 1.0, seed=177, ctx=ctx)
+    torch.cuda.synchronize()
+    assert np.allclose(init.cpu().numpy(), want0, rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("d", [1, 2, 9, 16, 64, 70, 200])
 @pytest.mark.parametrize("dist,nu", [("mvn", 0.0), ("mvt", 4.0), ("mvt", 2.5), ("mvt", 2.0)])
 def test_propagate_diagonal_models(cs, oracle, d, dist, nu):
@@ -906,6 +944,40 @@ def test_filter_against_oracle_larger(cs, oracle, d, dist, nu):
     assert np.array_equal(out["ancestors"], a), "%d of %d ancestors differ" % (int(np.sum(out["ancestors"] != a)), a.size)
     assert np.allclose(out["posterior_x"], X, rtol=1e-8, atol=1e-8)
     assert np.allclose(out["weights"], w, rtol=1e-6, atol=1e-300)
+
+
+@pytest.mark.parametrize("d,dist,nu", [(2, "mvn", 0.0), (7, "mvt", 4.0), (20, "mvn", 0.0), (64, "mvn", 0.0), (100, "mvt", 3.0),
+                                       (112, "mvn", 0.0), (150, "mvn", 0.0)])
+def test_filter_with_cholesky_factors(cs, oracle, monkeypatch, d, dist, nu):
+    """CUSMC_PROPOSAL_FACTOR=cholesky: run() takes the lower Cholesky factors of C0 and W as the proposals' square
+    roots instead of eigenSolver's V sqrt(Lambda) (src/mcmc.cpp:70-71, 280) -- the same law, and from d = 32 up the
+    triangular proposal kernels.  Against the oracle's step functions composed into MCMC()'s loop with those
+    factors; the default (eigen) form is what every other filter test covers.  An unknown value is refused."""
+    rng = np.random.default_rng(40 + d)
+    T, N = (6, 2000) if d <= 24 else (4, 600)
+    Y = rng.standard_normal((T, d))
+    G = 0.9 * np.eye(d) + 0.05 * rng.standard_normal((d, d)) / np.sqrt(max(d, 8) / 8)
+    F = np.eye(d) + 0.05 * rng.standard_normal((d, d)) / np.sqrt(max(d, 8) / 8)
+    V, W, C0 = spd(rng, d), 0.3 * spd(rng, d), spd(rng, d)
+    m0 = rng.standard_normal(d)
+    monkeypatch.setenv("CUSMC_PROPOSAL_FACTOR", "cholesky")
+    out = cs.run(N, d, T, Y.T, m0, C0, F, G, V, W, nu, "metropolis", dist, seed=9, return_ancestors=True)
+    Q0, Qw = np.linalg.cholesky(C0), np.linalg.cholesky(W)
+    X = np.zeros((T, N, d)); w = np.zeros((T, N)); a = np.zeros((T, N), np.uint32)
+    X[0], w[0] = oracle.initialize(N, m0, Q0, dist, nu, 1.0, seed=9, step=0)
+    for t in range(1, T):
+        a[t] = oracle.metropolis(w[t - 1], 10, 9, step=t)
+        X[t] = oracle.propagate(X[t - 1], a[t], G, Qw, dist, nu, 1.0, seed=9, step=t)
+        w[t] = np.exp(oracle.logpdf_hoisted(Y[t] - X[t] @ F.T, np.zeros(d), V, None, dist, nu))
+    assert np.array_equal(out["ancestors"], a)
+    assert np.allclose(out["posterior_x"], X, rtol=1e-8, atol=1e-8)
+    assert np.allclose(out["weights"], w, rtol=1e-6, atol=1e-300)
+    monkeypatch.setenv("CUSMC_PROPOSAL_FACTOR", "eigen")
+    ref = cs.run(N, d, T, Y.T, m0, C0, F, G, V, W, nu, "metropolis", dist, seed=9, return_ancestors=True)
+    assert not np.allclose(ref["posterior_x"][0], out["posterior_x"][0])  # (another square root: other realisations)
+    monkeypatch.setenv("CUSMC_PROPOSAL_FACTOR", "qr")
+    with pytest.raises(cs.CusmcError):
+        cs.run(N, d, T, Y.T, m0, C0, F, G, V, W, nu, "metropolis", dist, seed=9)
 
 
 @pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 4))
