@@ -179,7 +179,9 @@ int cusmc_metropolis_multi_host(const int *devices, int ndev, const double *w, u
  *     x_t[i] = [diag(c_i)] Q (scale * xi_i) + G x_prev[a[i]],   xi_i ~ N(0, I)
  * c_i,j = sqrt(nu / chi2_nu) per component for kind == CUSMC_MVT (src/statistics.cc.cpp:385-386,
  * 411).  Q is the dense square-root factor the caller supplies (eigenSolver:
- * src/linear_algebra.cpp:10-23, or cusmc_eigen_sqrt below).  scale = 1 draws from N(mu, QQ^T);
+ * src/linear_algebra.cpp:10-23, or cusmc_eigen_sqrt below); a Q whose upper triangle is zero (a Cholesky
+ * factor: the same law) is recognised and multiplied as a triangle -- half the matrix-core work of Q xi from
+ * d = 32 up, same values.  scale = 1 draws from N(mu, QQ^T);
  * scale = sqrt(3) reproduces the distribution of the reference's CPU transform
  * (src/statistics.cc.cpp:245-256).  a_dev == NULL means a[i] = i.
  * Rows [first, first+count) of the output are produced (X_out_dev has `count` rows) and key the
@@ -252,7 +254,10 @@ int cusmc_pf_step_dev(cusmc_dist *obs, int kind, float nu, const double *w_prev_
  * Outputs (host, any may be NULL): X T x N x d, w T x N (densities, unnormalised, as
  * run.rcpp.cpp:110-116 returns them), a T x N (row 0 unwritten in the reference; zeros here).
  * resampler must be "metropolis", distribution "mvn" or "mvt" (mcmc.cpp:252-266); anything
- * else is CUSMC_EINVAL (the reference throws bad_function_call). */
+ * else is CUSMC_EINVAL (the reference throws bad_function_call).
+ * The proposals' square roots of C0 and W are eigenSolver's, as MCMC() computes them (mcmc.cpp:70-71, 280);
+ * with CUSMC_PROPOSAL_FACTOR=cholesky in the environment they are the lower Cholesky factors instead (same
+ * law, other realisations; the triangular proposal kernels from d = 32 up). */
 int cusmc_pf_run_host(cusmc_ctx *ctx, const double *Y, uint32_t N, int d, uint32_t T,
                       const double *m0, const double *C0, const double *F, const double *G,
                       const double *V, const double *W, float df, const char *resampler,
