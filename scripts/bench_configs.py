@@ -96,24 +96,32 @@ def main():
         rows.append((name, "%.3g particles/s" % (N / t), "%.1f us" % (t * 1e6), "%.2f TB/s" % (N * (16 * d + 4) / t / 1e12), "-"))
         del Xp, anc, out
     # dense proposal draws (eigen-sqrt Q and a dense G, as a filter with a general model runs them)
-    for name, N, d, kind, nu in (("propagate dense MVN 1e6 x d=64", 1_000_000, 64, "mvn", 0.0),
-                                 ("propagate dense MVT(4) 1e6 x d=64", 1_000_000, 64, "mvt", 4.0),
-                                 ("C5 share propagate dense MVN 5e5 x d=256", 500_000, 256, "mvn", 0.0),
-                                 ("C5 share propagate dense MVT(4) 5e5 x d=256", 500_000, 256, "mvt", 4.0)):
+    # (and the same with Q lower triangular -- a Cholesky factor: Q xi over the k-blocks kb <= cb only)
+    for name, N, d, kind, nu, lower in (("propagate dense MVN 1e6 x d=64", 1_000_000, 64, "mvn", 0.0, False),
+                                        ("propagate dense MVT(4) 1e6 x d=64", 1_000_000, 64, "mvt", 4.0, False),
+                                        ("propagate dense G, lower Q MVN 1e6 x d=64", 1_000_000, 64, "mvn", 0.0, True),
+                                        ("propagate dense G, lower Q MVT(4) 1e6 x d=64", 1_000_000, 64, "mvt", 4.0, True),
+                                        ("C5 share propagate dense MVN 5e5 x d=256", 500_000, 256, "mvn", 0.0, False),
+                                        ("C5 share propagate dense MVT(4) 5e5 x d=256", 500_000, 256, "mvt", 4.0, False),
+                                        ("C5 share propagate dense G, lower Q MVN 5e5 x d=256", 500_000, 256, "mvn", 0.0, True),
+                                        ("C5 share propagate dense G, lower Q MVT(4) 5e5 x d=256", 500_000, 256, "mvt", 4.0, True)):
         rng = np.random.default_rng(d)
         Xp = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
         anc = torch.randint(0, N, (N,), dtype=torch.int32, device="cuda", generator=g)
         out = torch.empty(N, d, dtype=torch.float64, device="cuda")
         Gm = 0.9 * np.eye(d) + 0.1 * rng.standard_normal((d, d)) / np.sqrt(d)
         Q = 0.3 * np.eye(d) + 0.1 * rng.standard_normal((d, d)) / np.sqrt(d)
+        if lower:
+            Q = np.tril(Q)
         st = [0]
 
         def f():
             st[0] += 1
             cusmc_amd.api.propagate_dev(Xp, anc, Gm, Q, out, kind, nu, 1.0, seed=1, step=st[0], ctx=ctx)
         t = timed(f, 10, 2)
+        flops = 2.0 * d * d + (2.0 * 16 * (d // 16) * (16 * (d // 16) + 16) / 2 if lower else 2.0 * d * d)  # (block-triangular count)
         rows.append((name, "%.3g particles/s" % (N / t), "%.1f us" % (t * 1e6), "%.2f TB/s" % (N * (16 * d + 4) / t / 1e12),
-                     "%.1f TFLOP/s" % (N * 4.0 * d * d / t / 1e12)))
+                     "%.1f TFLOP/s" % (N * flops / t / 1e12)))
         del Xp, anc, out
     # one filter time step (resample + propagate + reweight), device-resident: fused launch vs three
     for name, N, d in (("C3 filter step N=1e6 d=2 B=10", 1_000_000, 2), ("filter step N=1e6 d=8 B=10", 1_000_000, 8)):

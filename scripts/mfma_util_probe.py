@@ -42,6 +42,7 @@ Q = 0.3 * np.eye(d) + 0.05 * np.random.default_rng(0).standard_normal((d, d))
 for i in range(5):
     cusmc_amd.api.propagate_dev(Xp, anc, 0.9 * np.eye(d) + 0.01 * Q, Q, out, "mvn", 0.0, 1.0, seed=1, step=i + 1, ctx=ctx)
     cusmc_amd.api.propagate_dev(Xp, anc, 0.9 * np.eye(d), Q, out, "mvn", 0.0, 1.0, seed=1, step=i + 1, ctx=ctx)
+    cusmc_amd.api.propagate_dev(Xp, anc, 0.9 * np.eye(d) + 0.01 * Q, np.tril(Q), out, "mvn", 0.0, 1.0, seed=1, step=i + 1, ctx=ctx)  # (TRIQ)
 torch.cuda.synchronize()
 # the wide proposal kernel (128 < d <= 256): dense and diagonal G, Normal and Student-t
 for N, d in ((250_000, 256), (250_000, 192), (250_000, 144)):
@@ -55,5 +56,6 @@ for N, d in ((250_000, 256), (250_000, 192), (250_000, 144)):
         for kind, nu in (("mvn", 0.0), ("mvt", 4.0)):
             cusmc_amd.api.propagate_dev(Xp, anc, Gm, Q, out, kind, nu, 1.0, seed=1, step=i + 1, ctx=ctx)
             cusmc_amd.api.propagate_dev(Xp, anc, np.diag(np.diag(Gm)), Q, out, kind, nu, 1.0, seed=1, step=i + 1, ctx=ctx)
+            cusmc_amd.api.propagate_dev(Xp, anc, Gm, np.tril(Q), out, kind, nu, 1.0, seed=1, step=i + 1, ctx=ctx)  # (TRIQ)
     torch.cuda.synchronize()
     del Xp, anc, out
