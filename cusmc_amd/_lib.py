@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libcusmc_hip.so")
+# (CUSMC_LIBRARY: another build of the same ABI -- a sanitizer or calibration build; scripts/host_sanitizers.sh)
+SO_PATH = os.environ.get("CUSMC_LIBRARY") or os.path.join(_HERE, "libcusmc_hip.so")
 
 OK, EINVAL, ENOTSPD, EHIP, ENODEVICE, ERANGE = range(6)
 MVN, MVT = 0, 1
