@@ -40,6 +40,10 @@
 #include "../launch.h"
 #include "../../../include/cusmc_hip.h"
 
+#ifndef CUSMC_WIDE_DMA_AUX  // cache-policy bits of the loader's LDS-DMA loads (calibration builds: 2 = nt, 16 = sc1, 1 = sc0)
+#define CUSMC_WIDE_DMA_AUX 0
+#endif
+
 namespace cusmc {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 #pragma unroll
           for (int t = 0; t < TILES; ++t) {
             auto *dst = (__attribute__((address_space(3))) void *)(buf + ((kb * 2 + h2) * TILES + t) * 128);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, t * tile_bytes + 128 * kb + 64 * h2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, t * tile_bytes + 128 * kb + 64 * h2, 0, CUSMC_WIDE_DMA_AUX);
             // Pace the stream: issued as one burst, the group's 64 KB of HBM reads sit in the CU's
             // vector-memory path in front of the compute waves' fragment loads, which then see
             // HBM latency instead of L2 latency (full kernel 672 -> 642 us in the calibration run
