@@ -493,8 +493,8 @@ int run_sharded(int n, F &&fn)
 
 // ---- library / context ----------------------------------------------------------------------
 
-CUSMC_EXPORT const char *cusmc_version(void) { return "cusmc-hip 0.3 (gfx950; rng contract 3)"; }
-CUSMC_EXPORT int cusmc_rng_contract(void) { return 3; }
+CUSMC_EXPORT const char *cusmc_version(void) { return "cusmc-hip 0.3 (gfx950; rng contract 4)"; }
+CUSMC_EXPORT int cusmc_rng_contract(void) { return 4; }
 
 // One independent Philox key per R-level call: the (call + 1)-th output of SplitMix64 seeded with
 // `seed`.  The R-level draw / resample / run() entry points have no seed argument (the reference

@@ -98,9 +98,10 @@ __global__ __launch_bounds__(T) void propagate_kernel(
 // spills: 540 .. 830 us)
 constexpr int kDiagRows = 4;
 
-// CHI: 0 Normal; 1, 2 Student-t with the closed-form chi^2 of nu = 2, 4 (RNG contract 2: one more Philox block and two
-// ln per pair, no rejection -- same loop as the Normal draw); 3 Student-t by Marsaglia-Tsang (any other nu), PPL pairs
-// of a row per lane and trip
+// CHI: 0 Normal; 1, 2 Student-t with the closed-form chi^2 of nu = 2, 4 (one more Philox block and two ln per pair, no
+// rejection -- same loop as the Normal draw); 4: the closed form of any other integer nu <= 16 (RNG contract 4:
+// ceil(nu / 4) blocks of uniforms, a Box-Muller pair for odd nu), same loop; 3 Student-t by Marsaglia-Tsang (any other
+// nu), PPL pairs of a row per lane and trip
 template <int CHI, int PPL = 4>
 __global__ __launch_bounds__(256) void propagate_diag_kernel(
     float nu, const double *__restrict__ X_prev, const uint32_t *__restrict__ a,
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(256) void propagate_diag_kernel(
           double s0 = fma(q0, scale * z0, 0.0), s1 = fma(q1, scale * z1, 0.0);
           if constexpr (MVT) {
             double c0, c1;
-            chi_closed_pair<CHI>(first + il[u], (uint32_t)pr, step, k0, k1, c0, c1);
+            if constexpr (CHI == 4) chi_closed_pair_any(cs, first + il[u], (uint32_t)pr, step, k0, k1, c0, c1);
+            else chi_closed_pair<CHI>(first + il[u], (uint32_t)pr, step, k0, k1, c0, c1);
             s0 = fma(s0, sqrt((double)nu / c0), 0.0);  // (an fma, so that no kernel contracts it with the add below)
             s1 = fma(s1, sqrt((double)nu / c1), 0.0);
           }
@@ -235,7 +237,7 @@ hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const
   const int pairs = (d + 1) / 2;
   int pw_log2 = 0;
   while ((1 << pw_log2) < pairs && pw_log2 < 8) ++pw_log2;
-  const int chi = kind != CUSMC_MVT ? 0 : nu == 2.0f ? 1 : nu == 4.0f ? 2 : 3;  // (smallops.h: chi_setup)
+  const int chi = kind != CUSMC_MVT ? 0 : nu == 2.0f ? 1 : nu == 4.0f ? 2 : chi_nu_closed(nu) ? 4 : 3;  // (smallops.h: chi_setup)
   const bool four = chi == 3 && pairs >= 4;
   if (four) pw_log2 -= 2;  // four pairs per lane: eight chi^2 draws per batch
   const long rows_per_block = (long)(256 >> pw_log2) * (chi != 3 ? kDiagRows : 1);  // (four rows per lane and trip)
@@ -243,7 +245,7 @@ hipError_t launch_propagate_diag(int kind, float nu, const double *X_prev, const
   const long cap = (long)num_cus * 8;
   if (blocks > cap) blocks = cap;
   auto kern = chi == 0 ? propagate_diag_kernel<0> : chi == 1 ? propagate_diag_kernel<1> : chi == 2 ? propagate_diag_kernel<2>
-              : four ? propagate_diag_kernel<3, 4> : propagate_diag_kernel<3, 1>;
+              : chi == 4 ? propagate_diag_kernel<4> : four ? propagate_diag_kernel<3, 4> : propagate_diag_kernel<3, 1>;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, nu, X_prev, a, gdiag, qdiag, m0, d,
                      pw_log2, scale, (uint32_t)seed, (uint32_t)(seed >> 32), step, domain, first, count, X_out);
   return hipGetLastError();

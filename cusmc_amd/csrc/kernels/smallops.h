@@ -105,13 +105,16 @@ static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, do
   z1 = rad * s;
 }
 
-// chi^2_nu draws, RNG CONTRACT 2 (restated in oracle/cusmc_oracle.c:chi_square_for).
+// chi^2_nu draws, RNG CONTRACT 4 (restated in oracle/cusmc_oracle.c:chi_square_for).
 // Law: chi[j] ~ chi^2_nu per component, independent of each other and of the normals
 // (src/statistics.cc.cpp:366, 383-386; device helper src/mvt_dist.cu.cpp:20-61).  Keyed by the component PAIR
 // p = j / 2, half e = j % 2 -- the unit the proposal normals are keyed by:
-//   nu == 2 or 4   closed form chi^2_{2m} = -2 ln(u_1 .. u_m): ONE block (particle, p, step, 6) per pair, half e
-//                  takes words (2e, 2e+1) -- m = 1: one 52-bit uniform, m = 2: two 32-bit uniforms, all in (0, 1).
-//                  No rejection, no divergent branch.
+//   integer nu <= 16   closed form, m = nu / 2 (rounded down):  chi^2_nu = -2 ln(u_1 .. u_m) [+ z^2 if nu is odd].
+//                  Block b < ceil(m / 2) of the pair: (particle, p + (b << 16), step, 6); half e takes its words
+//                  (2e, 2e+1) as u_{2b+1}, u_{2b+2} -- m = 1: ONE 52-bit uniform from both words, m >= 2: 32-bit
+//                  uniforms, all in (0, 1), multiplied in that order.  Odd nu: (z_0, z_1) = Box-Muller of block
+//                  (particle, p, step, 8), half e adds z_e^2 by fma.  No rejection, no divergent branch.
+//                  (Contract 2 / 3 had this for nu = 2 and 4 only; their draws are unchanged.)
 //   other nu       Marsaglia-Tsang, squeeze and a < 1 boost as the reference's helper.  Attempt m < 63 of pair p:
 //                  block (particle, 64 p + m, step, 3) -> Box-Muller -> (z0, z1) = the normals of halves (0, 1);
 //                  block (particle, 64 p + m, step, 5) -> words (2e, 2e+1) -> half e's uniform in (0, 1].  Accept iff
@@ -128,13 +131,19 @@ static __device__ __forceinline__ void normal_pair(const u32x4 r, double &z0, do
 struct ChiSquare {
   double dd, c, inv_a;
   bool boost;
-  int closed;  // 0: Marsaglia-Tsang; 1, 2: closed form with m = nu / 2 uniforms per component
+  int closed;  // 0: Marsaglia-Tsang; 1: closed form with m uniforms per component, plus a squared normal if odd
+  int m;
+  bool odd;
 };
+// which nu take the closed form (the launchers pick kernel variants by it)
+__host__ __device__ __forceinline__ bool chi_nu_closed(float nu) { return nu >= 1.0f && nu <= 16.0f && nu == (float)(int)nu; }
 static __device__ __forceinline__ ChiSquare chi_setup(float nu)
 {
   ChiSquare cs;
   double a = 0.5 * (double)nu;
-  cs.closed = nu == 2.0f ? 1 : nu == 4.0f ? 2 : 0;
+  cs.closed = chi_nu_closed(nu) ? 1 : 0;
+  cs.m = cs.closed ? (int)nu / 2 : 0;
+  cs.odd = cs.closed && ((int)nu & 1);
   cs.boost = a < 1.0;
   cs.inv_a = 1.0 / a;
   if (cs.boost) a += 1.0;
@@ -158,6 +167,36 @@ static __device__ __forceinline__ void chi_closed_pair(uint32_t particle, uint32
   }
   chi0 = -2.0 * ln_pos(P0);
   chi1 = -2.0 * ln_pos(P1);
+}
+// any integer nu <= 16 (cs.m, cs.odd wave-uniform: nu is a launch parameter)
+static __device__ __forceinline__ void chi_closed_pair_any(const ChiSquare &cs, uint32_t particle, uint32_t p, uint32_t step,
+                                                           uint32_t k0, uint32_t k1, double &chi0, double &chi1)
+{
+  double P0 = 1.0, P1 = 1.0;
+  if (cs.m == 1) {
+    const u32x4 r = philox4x32_10(particle, p, step, 6u, k0, k1);
+    P0 = ((double)(((((uint64_t)r.x << 32) | r.y)) >> 12) + 0.5) * 0x1.0p-52;
+    P1 = ((double)(((((uint64_t)r.z << 32) | r.w)) >> 12) + 0.5) * 0x1.0p-52;
+  } else {
+#pragma unroll 1
+    for (int b = 0; 2 * b < cs.m; ++b) {
+      const u32x4 r = philox4x32_10(particle, p + ((uint32_t)b << 16), step, 6u, k0, k1);
+      P0 *= fma((double)r.x, 0x1.0p-32, 0x1.0p-33);
+      P1 *= fma((double)r.z, 0x1.0p-32, 0x1.0p-33);
+      if (2 * b + 1 < cs.m) {
+        P0 *= fma((double)r.y, 0x1.0p-32, 0x1.0p-33);
+        P1 *= fma((double)r.w, 0x1.0p-32, 0x1.0p-33);
+      }
+    }
+  }
+  chi0 = cs.m ? -2.0 * ln_pos(P0) : 0.0;
+  chi1 = cs.m ? -2.0 * ln_pos(P1) : 0.0;
+  if (cs.odd) {
+    double z0, z1;
+    normal_pair(philox4x32_10(particle, p, step, 8u, k0, k1), z0, z1);
+    chi0 = fma(z0, z0, chi0);
+    chi1 = fma(z1, z1, chi1);
+  }
 }
 // attempt m of pair p: the two normals, v = 1 + c z and the two uniforms in (0, 1]
 static __device__ __forceinline__ void chi_attempt_pair(const ChiSquare &cs, uint32_t particle, uint32_t pm, uint32_t step,
@@ -238,8 +277,9 @@ static __device__ __forceinline__ void chi_pair_batch(const ChiSquare &cs, uint3
     for (int c = 0; c < KP; ++c) {
       if (!live(c)) continue;
       double g0, g1;
-      if (cs.closed == 1) chi_closed_pair<1>(particle, (uint32_t)pof(c), step, k0, k1, g0, g1);
-      else chi_closed_pair<2>(particle, (uint32_t)pof(c), step, k0, k1, g0, g1);
+      if (cs.m == 1 && !cs.odd) chi_closed_pair<1>(particle, (uint32_t)pof(c), step, k0, k1, g0, g1);
+      else if (cs.m == 2 && !cs.odd) chi_closed_pair<2>(particle, (uint32_t)pof(c), step, k0, k1, g0, g1);
+      else chi_closed_pair_any(cs, particle, (uint32_t)pof(c), step, k0, k1, g0, g1);
 #pragma unroll
       for (int cc = 0; cc < KP; ++cc) {
         chi[2 * cc] = cc == c ? g0 : chi[2 * cc];

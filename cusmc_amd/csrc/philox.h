@@ -15,6 +15,8 @@
 //             3 chi-square normals sub = j*64 + attempt
 //             4 initial normals    sub = component pair
 //             5 chi-square accept / boost uniforms
+//             6 chi-square closed form (integer nu <= 16): uniforms, sub = pair + (block << 16)
+//             8 chi-square closed form, odd nu: the pair's two normals, sub = pair
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -72,7 +72,9 @@ const char *cusmc_version(void);
  * 2 (round 3): chi-square draws keyed by the component pair -- closed form for nu = 2, 4, pair-shared
  * Marsaglia-Tsang attempts otherwise.  3 (round 3): the resampler takes ONE Philox block per TWO chain steps (32
  * leading bits of u and a 32-bit index candidate per step, both completed exactly from further blocks in the rare
- * cases where they cannot decide); everything else as contract 1.  (The reference has no contract: it
+ * cases where they cannot decide); everything else as contract 1.  4 (round 3): the closed-form chi-square
+ * draw for every integer nu <= 16 (products of nu / 2 uniforms, a squared normal on top for odd nu); nu = 2, 4
+ * and every non-integer nu draw what contract 3 drew.  (The reference has no contract: it
  * reseeds from std::random_device per call, src/statistics.cc.cpp:231-232, 360-361.) */
 int cusmc_rng_contract(void);
 const char *cusmc_last_error(void);

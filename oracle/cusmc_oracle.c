@@ -342,7 +342,8 @@ ORACLE_API int oracle_logpdf_hoisted(const double *X, long N, long ldx, const do
  *   key     = (seed_lo, seed_hi)
  *   counter = (index, sub, step, domain)
  * domain tags: 1 resampler, 2 proposal normals, 3 chi-square normals, 4 initial normals,
- *              5 chi-square accept/boost uniforms, 6 chi-square closed-form uniforms (contract 2: see
+ *              5 chi-square accept/boost uniforms, 6 chi-square closed-form uniforms, 8 the closed form's normals
+ *              for odd nu (contract 4: see
  *              chi_square_for), 7 resampler accept refinement, 16 + q resampler index redraws (contract 3).
  * ---------------------------------------------------------------------------------------- */
 #define PHILOX_M0 0xD2511F53u
@@ -539,7 +540,8 @@ static void normals_for(uint32_t particle, uint32_t step, uint32_t domain, const
   }
 }
 
-/* chi^2_nu draws, RNG CONTRACT 2 (round 3; contract 1 keyed two Philox blocks and a whole Box-Muller pair per
+/* chi^2_nu draws, RNG CONTRACT 4 (contract 2 of round 3, closed form extended from nu = 2, 4 to every integer
+ * nu <= 16; contract 1 keyed two Philox blocks and a whole Box-Muller pair per
  * attempt and component and threw the second normal and half of the uniforms away -- 3 to 4.6 x the cost of
  * the Normal draw on the GPU).  The reference's draws cannot be reproduced by anyone (std::random_device per
  * call, src/statistics.cc.cpp:360-361; curand_init(dev_seed, ...) with a wall-clock seed on the device path), so
@@ -547,12 +549,16 @@ static void normals_for(uint32_t particle, uint32_t step, uint32_t domain, const
  * (src/statistics.cc.cpp:366, 383-386: `chi[j] = X2(generator)` per component).  Everything is keyed by the
  * component PAIR p = j / 2, half e = j % 2 -- the unit the proposal normals are keyed by as well:
  *
- *   nu == 2 or nu == 4 (exactly)   closed form, no rejection:  chi^2_{2m} = -2 ln(u_1 ... u_m), m = nu / 2.
- *       ONE block (particle, p, step, 6) per pair; half e takes words (2e, 2e+1):
- *         m = 1:  u = ((w_2e : w_2e+1) >> 12 + 1/2) 2^-52                       in (0, 1), 52 bits
- *         m = 2:  u_1 = (w_2e + 1/2) 2^-32,  u_2 = (w_2e+1 + 1/2) 2^-32         in (0, 1), 32 bits each
- *       (32-bit uniforms at m = 2: the product has 2^64 equally likely values; the largest draw is 91.5 where
- *       the exact law has 6e-19 beyond it, the smallest 4.7e-10 with 3e-20 below it)
+ *   integer nu <= 16   closed form, no rejection, m = floor(nu / 2):
+ *           chi^2_nu = -2 ln(u_1 ... u_m)  [ + z^2 if nu is odd ]
+ *       Block b < ceil(m / 2) of the pair: (particle, p + (b << 16), step, 6); half e takes its words (2e, 2e+1):
+ *         m = 1:  u = ((w_2e : w_2e+1) >> 12 + 1/2) 2^-52                                   in (0, 1), 52 bits
+ *         m >= 2: u_{2b+1} = (w_2e + 1/2) 2^-32,  u_{2b+2} = (w_2e+1 + 1/2) 2^-32 (if <= m)  in (0, 1), 32 bits each,
+ *                 multiplied in that order starting from 1.0
+ *       odd nu: (z_0, z_1) = Box-Muller of block (particle, p, step, 8); half e adds z_e^2 (one fma).
+ *       (32-bit uniforms: at m = 2 the product has 2^64 equally likely values; the largest draw is 91.5 where
+ *       the exact law has 6e-19 beyond it, the smallest 4.7e-10 with 3e-20 below it.  nu = 2 and 4 are what
+ *       contracts 2 and 3 drew.)
  *   any other nu   Marsaglia-Tsang as the reference's device helper (src/mvt_dist.cu.cpp:20-61; libstdc++'s
  *       gamma_distribution behind chi_squared_distribution on the CPU path is the same algorithm), squeeze
  *       included, a < 1 boost included.  Attempt m < 63 of pair p: block (particle, 64 p + m, step, 3) ->
@@ -564,17 +570,31 @@ static double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, const
                              float nu)
 {
   const uint32_t p = j >> 1, e = j & 1u;
-  if (nu == 2.0f || nu == 4.0f) {
-    uint32_t ctr[4] = {particle, p, step, 6u}, r[4];
-    oracle_philox4x32_10(ctr, key, r);
-    double P;
-    if (nu == 2.0f) {
+  if (nu >= 1.0f && nu <= 16.0f && nu == (float)(int)nu) {
+    const int m = (int)nu / 2, odd = (int)nu & 1;
+    double P = 1.0, chi = 0.0;
+    if (m == 1) {
+      uint32_t ctr[4] = {particle, p, step, 6u}, r[4];
+      oracle_philox4x32_10(ctr, key, r);
       const uint64_t v = (((uint64_t)r[2 * e] << 32) | r[2 * e + 1]) >> 12;
       P = ((double)v + 0.5) * 0x1.0p-52;
     } else {
-      P = fma((double)r[2 * e], 0x1.0p-32, 0x1.0p-33) * fma((double)r[2 * e + 1], 0x1.0p-32, 0x1.0p-33);
+      for (int b = 0; 2 * b < m; ++b) {
+        uint32_t ctr[4] = {particle, p + ((uint32_t)b << 16), step, 6u}, r[4];
+        oracle_philox4x32_10(ctr, key, r);
+        P *= fma((double)r[2 * e], 0x1.0p-32, 0x1.0p-33);
+        if (2 * b + 1 < m) P *= fma((double)r[2 * e + 1], 0x1.0p-32, 0x1.0p-33);
+      }
     }
-    return -2.0 * log(P);
+    if (m) chi = -2.0 * log(P);
+    if (odd) {
+      uint32_t ctr[4] = {particle, p, step, 8u}, r[4];
+      double zz[2];
+      oracle_philox4x32_10(ctr, key, r);
+      normal_pair(r, &zz[0], &zz[1]);
+      chi = fma(zz[e], zz[e], chi);
+    }
+    return chi;
   }
   double a = 0.5 * (double)nu;
   double boost = 1.0;
@@ -607,7 +627,7 @@ static double chi_square_for(uint32_t particle, uint32_t j, uint32_t step, const
   return 2.0 * g * boost;
 }
 
-ORACLE_API int oracle_rng_contract(void) { return 3; }
+ORACLE_API int oracle_rng_contract(void) { return 4; }
 
 /* chi^2 draws of components [0, d) of `count` particles starting at `first` (tests/test_distributions.py holds
  * them against the exact chi^2_nu law; the kernels never see this) */
