@@ -57,8 +57,9 @@ def check_covariance(draw_q, eigen_sqrt):
 
 def check_student(draw_t):
     """draw_t(count, nu, seed) -> count x 2 draws with mu = 0, Q = I: two INDEPENDENT t_nu marginals (F7)"""
-    # 0.75, 1.5: the a < 1 boost of the gamma sampler (src/mvt_dist.cu.cpp:53-60); 2, 4: RNG contract 2's closed forms
-    for nu in (0.75, 1.5, 2.0, 3.0, 4.0, 30.0):
+    # 0.75, 1.5: the a < 1 boost of the gamma sampler (src/mvt_dist.cu.cpp:53-60); 2.5, 30: Marsaglia-Tsang; the
+    # integers: RNG contract 4's closed forms (1: a squared normal alone; 3, 7: uniforms and a squared normal)
+    for nu in (0.75, 1.0, 1.5, 2.0, 2.5, 3.0, 4.0, 7.0, 30.0):
         X = draw_t(200_000, nu, 13)
         for j in range(2):
             assert ks_p(X[:, j], stats.t(nu)) > P_MIN, (nu, j)
@@ -147,7 +148,7 @@ def test_oracle_student_marginals(oracle):
 
 def check_chi_square(draw):
     """draw(count, d, nu, seed) -> count x d chi-square draws: every component chi^2_nu, components independent --
-    in particular the two halves of a component pair, which RNG contract 2 feeds from the same Philox blocks."""
+    in particular the two halves of a component pair, which the RNG contract feeds from the same Philox blocks."""
     # (integer nu <= 16: closed forms -- products of 1 .. 8 uniforms, a squared normal on top for odd nu; 17 and
     # the fractional ones: Marsaglia-Tsang)
     for nu in (0.5, 1.0, 2.0, 2.5, 3.0, 4.0, 5.0, 6.0, 7.0, 11.0, 15.0, 16.0, 17.0, 30.0):
@@ -219,12 +220,12 @@ def test_gpu_student_marginals(cs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nu", [4.0, 2.0, 3.0])
+@pytest.mark.parametrize("nu", [4.0, 2.0, 3.0, 2.5])
 @pytest.mark.parametrize("d", [16, 64, 256])
 def test_gpu_student_marginals_matrix_core_kernels(cs, d, nu):
     """The same law out of the matrix-core proposal kernels (d = 16, 64: propagate_mfma_kernel; d = 256:
     propagate_wide_kernel): two of the d components tested per kernel, chi-square per component -- nu = 4, 2: the
-    closed forms, 3: Marsaglia-Tsang, all three through the lane exchange of the C layout (chi_square_clayout).
+    closed forms of even nu, 3: a closed form of odd nu, 2.5: Marsaglia-Tsang, all through the lane exchange of the C layout (chi_square_clayout).
     Q is block diagonal with a rotation in every 2 x 2 block (Q Q^T = I, but NOT diagonal: a diagonal Q would
     take propagate_diag_kernel)."""
     c, s = np.cos(0.3), np.sin(0.3)
