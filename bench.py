@@ -21,7 +21,8 @@ mismatch can no longer measure one GPU and call it N.
 Prints ONE JSON line on rank 0 (contract: the task statement; roofline terms: DESIGN.md).  Beyond the
 contract's keys the line carries `strong` (fixed-total-work legs: the headline's 1e6 x 64 and
 BASELINE configs[4]'s 4e6 x 256 split over the ranks), `mh` (configs[1], weight all-gather timed) and
-`filter_step` (one sharded bootstrap-filter step with its two exchanges timed).
+`filter_step` (one sharded bootstrap-filter step with its two exchanges timed) and `proposal` (propagate_K's draws
+for the headline shape, dense G, Q full or a Cholesky factor, Normal and Student-t).
 """
 import argparse
 import json
@@ -304,6 +305,7 @@ def main():
             "mh": None,
             "strong": None,
             "filter_step": None,
+            "proposal": None,
             "ranks": int(dist.get_world_size()) if dist_on else world,
             "backend": dist.get_backend() if dist_on else "single process",
             "parity_max_rel_err_vs_oracle": None,
@@ -475,6 +477,30 @@ def main():
     except Exception as exc:  # noqa: BLE001
         filt = aux_failed("filter_step", exc)
 
+    # The proposal draws north_star names ("the MVN proposal RNG"): propagate_K's x_t = Q xi + G x_{t-1}[a] for the
+    # headline shape, every rank its own 1e6 x 64 particles (weak, no collective), dense G; Q once as eigenSolver's full
+    # square root and once as a Cholesky factor (multiplied as a triangle), Normal and Student-t (nu = 4).
+    prop = None
+    try:
+        rngp = np.random.default_rng(64)
+        Gp = 0.9 * np.eye(D) + 0.1 * rngp.standard_normal((D, D)) / np.sqrt(D)
+        Sp = make_sigma(D, 6)
+        Qe, Qc = cusmc_amd.eigenSolver(Sp), np.linalg.cholesky(Sp)
+        anc = torch.randint(0, N_PER_GPU, (N_PER_GPU,), dtype=torch.int32, device="cuda", generator=g)
+        Xo = torch.empty_like(X)
+        stp = [0]
+        prop = {"particles_per_gpu": N_PER_GPU, "d": D}
+        for key, Qm, kind, nu in (("mvn_full_q", Qe, "mvn", 0.0), ("mvn_cholesky_q", Qc, "mvn", 0.0),
+                                  ("mvt4_full_q", Qe, "mvt", 4.0), ("mvt4_cholesky_q", Qc, "mvt", 4.0)):
+            def draw(Qm=Qm, kind=kind, nu=nu):
+                stp[0] += 1
+                cusmc_amd.api.propagate_dev(X, anc, Gp, Qm, Xo, kind, nu, 1.0, seed=5, step=stp[0], ctx=mvn.ctx)
+            s_p = timed_max(draw, 40, warm=20)
+            prop[key] = {"us_per_launch": s_p * 1e6, "particles_per_s": world * N_PER_GPU / s_p}
+        del anc, Xo
+    except Exception as exc:  # noqa: BLE001
+        prop = aux_failed("proposal", exc)
+
     # The CPU leg is the only place bench.py touches oracle/: it times the reference-faithful port
     # and, while it has it loaded, checks the sample of the GPU's outputs against it.
     cpu, parity = None, None
@@ -486,7 +512,7 @@ def main():
 
     if rank == 0:
         line.update({"cpu_baseline": cpu, "mh_steps_per_s": None if not mh else mh.get("steps_per_s"), "mh": mh,
-                     "strong": strong, "filter_step": filt, "parity_max_rel_err_vs_oracle": parity})
+                     "strong": strong, "filter_step": filt, "proposal": prop, "parity_max_rel_err_vs_oracle": parity})
         emit()
     if dist_on:
         dist.barrier()
