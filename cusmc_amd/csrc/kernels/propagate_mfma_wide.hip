@@ -269,7 +269,6 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
         product(One{}, M0{}, std::true_type{}, frags, 0, cb0 + 1);
       }
     };
-    auto multiply = [&](const double *__restrict__ frags) { multiply_dense(frags); };
     if constexpr (TRIQ) multiply_tri(fragsQ);
     else multiply_dense(fragsQ);
     PW_STAMP(3);
@@ -319,7 +318,7 @@ __global__ __launch_bounds__(512) void propagate_wide_kernel(
       for (int kb = 0; kb < NB; ++kb) reinterpret_cast<v2d *>(sB + (w + 8 * kb) * 128)[lane] = xg[kb];
       PW_STAMP(4);
       __syncthreads();
-      multiply(tail);
+      multiply_dense(tail);  // (G is a general matrix)
     }
     PW_STAMP(5);
     if constexpr (HAS_G && !MVT) {
