@@ -973,6 +973,10 @@ def test_filter_with_cholesky_factors(cs, oracle, monkeypatch, d, dist, nu):
     assert np.array_equal(out["ancestors"], a)
     assert np.allclose(out["posterior_x"], X, rtol=1e-8, atol=1e-8)
     assert np.allclose(out["weights"], w, rtol=1e-6, atol=1e-300)
+    # the sharded loop takes the same factors (two shards on device 0): bitwise the one-device run
+    two = cs.run(N, d, T, Y.T, m0, C0, F, G, V, W, nu, "metropolis", dist, seed=9, return_ancestors=True, devices=[0, 0])
+    for key in ("posterior_x", "weights", "ancestors"):
+        assert np.array_equal(two[key], out[key]), key
     monkeypatch.setenv("CUSMC_PROPOSAL_FACTOR", "eigen")
     ref = cs.run(N, d, T, Y.T, m0, C0, F, G, V, W, nu, "metropolis", dist, seed=9, return_ancestors=True)
     assert not np.allclose(ref["posterior_x"][0], out["posterior_x"][0])  # (another square root: other realisations)
