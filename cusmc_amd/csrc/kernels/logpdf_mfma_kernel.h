@@ -47,19 +47,9 @@ __host__ __device__ constexpr int pi_k(int s, int h) { return 2 * h + (s & 1) + 
 
 __device__ __forceinline__ double finish(double q, const Epilogue &ep)
 {
-  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p(q * ep.inv_nu)
+  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p_nonneg(q * ep.inv_nu)
                                      : ep.lognorm - 0.5 * q;
   return ep.out_density ? exp(lp) : lp;
-}
-
-// log1p(t) for t >= 0 (q / nu): ln(1 + t) plus the first-order correction for the rounding of
-// 1 + t; Inf and NaN pass through.
-__device__ __forceinline__ double log1p_nonneg(double t)
-{
-  const double u = 1.0 + t;
-  const double c = (t - (u - 1.0)) * __builtin_amdgcn_rcp(u);
-  const double r = ln_pos(u) + c;
-  return u < __builtin_inf() ? r : u;
 }
 
 template <int EPI>

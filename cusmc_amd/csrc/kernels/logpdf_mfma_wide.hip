@@ -39,6 +39,7 @@
 
 #include "../launch.h"
 #include "../../../include/cusmc_hip.h"
+#include "smallops.h"
 
 #ifndef CUSMC_WIDE_DMA_AUX  // cache-policy bits of the loader's LDS-DMA loads (calibration builds: 2 = nt, 16 = sc1, 1 = sc0)
 #define CUSMC_WIDE_DMA_AUX 0
@@ -83,6 +84,24 @@ __host__ __device__ constexpr WideMap wide_map(int nb)
     if (n == 4) { m.lo[s] = blk[s][3]; m.lo[s + 4] = blk[s][2]; }
   }
   return m;
+}
+// The wave that adds up a group's partial sums and runs the epilogue: the older wave (w < 4) of the LEAST loaded SIMD.
+// Its ~20 (Normal) .. ~80 (Student-t) dependent VALU instructions issue one per gap between the other waves' 64-cycle
+// MFMAs -- thousands of cycles -- and on the most loaded SIMD (wave 0's, where the map puts the largest block) that
+// lands on the group's critical path: Student-t at NB = 12 cost 22 % more than Normal with wave 0 doing it.
+__host__ __device__ constexpr int wide_epilogue_wave(int nb)
+{
+#ifdef CUSMC_WIDE_EPILOGUE_WAVE  // (calibration builds: a fixed wave, e.g. 0 = rounds 1 - 2)
+  return (void)nb, CUSMC_WIDE_EPILOGUE_WAVE;
+#endif
+  const WideMap m = wide_map(nb);
+  int best = 0, best_load = 1 << 30;
+  for (int s = 0; s < 4; ++s) {
+    int load = 0;
+    for (int w = s; w < 8; w += 4) load += (m.lo[w] + 1) + (m.hi[w] + 1);
+    if (load <= best_load) { best_load = load; best = s; }  // (ties: the last SIMD)
+  }
+  return best;
 }
 __host__ __device__ constexpr int wide_lo(int nb, int w) { return wide_map(nb).lo[w]; }
 __host__ __device__ constexpr int wide_hi(int nb, int w) { return wide_map(nb).hi[w]; }
@@ -153,7 +172,7 @@ void mfma_wide_pack_frags(const double *M, int d, double *frags)
 
 static __device__ __forceinline__ double finish_wide(double q, const Epilogue &ep)
 {
-  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p(q * ep.inv_nu)
+  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p_nonneg(q * ep.inv_nu)
                                      : ep.lognorm - 0.5 * q;
   return ep.out_density ? exp(lp) : lp;
 }
@@ -426,7 +445,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
     LW_STAMP(1);
     __syncthreads();  // partials visible; the loader has completed the other buffer
     LW_STAMP(2);
-    if (w == 0 && lane < GP) {  // fixed summation order over the waves -> bitwise reproducible
+    if (w == wide_epilogue_wave(NB) && lane < GP) {  // fixed summation order over the waves -> bitwise reproducible
       const double *sp = sPartial + parity * WAVES * GP + lane;
       double tot = sp[0];
 #pragma unroll

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kPercovLanes) void logpdf_percov_kernel(
       z[j] = t / a.get(tri_index(j, j));
       q = fma(z[j], z[j], q);
     }
-    double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p(q * ep.inv_nu) : ep.lognorm - 0.5 * q;
+    double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p_nonneg(q * ep.inv_nu) : ep.lognorm - 0.5 * q;
     lp -= 0.5 * ld;
     out[i] = bad ? __builtin_nan("") : (ep.out_density ? exp(lp) : lp);
     if (info) info[i] = bad;

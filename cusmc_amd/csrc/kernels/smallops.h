@@ -58,6 +58,17 @@ static __device__ __forceinline__ double ln_pos(double x)
   return dk * ln2_hi - ((hfsq - (sq * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
+// log1p(t) for t >= 0 (the Student-t epilogue's q / nu): ln(1 + t) plus the first-order correction for the rounding
+// of 1 + t; Inf and NaN pass through.  (The library log1p also serves t in (-1, 0) and costs four times the
+// instructions.)
+static __device__ __forceinline__ double log1p_nonneg(double t)
+{
+  const double u = 1.0 + t;
+  const double c = (t - (u - 1.0)) * __builtin_amdgcn_rcp(u);
+  const double r = ln_pos(u) + c;
+  return u < __builtin_inf() ? r : u;
+}
+
 // cos(2 pi u), sin(2 pi u) for u in [0, 1): exact reduction to a quadrant (2u = q/2 + r,
 // |r| <= 1/4), then fdlibm's k_sin.c / k_cos.c kernels on x = pi r, |x| <= pi/4 (constants from
 // there).  No Payne-Hanek path, no double-double: < 1.5 ulp on both.
@@ -628,7 +639,7 @@ static __device__ __forceinline__ uint32_t metropolis_chain_log(const double *__
 
 static __device__ __forceinline__ double finish_generic(double q, const Epilogue &ep)
 {
-  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p(q * ep.inv_nu)
+  double lp = (ep.kind == CUSMC_MVT) ? ep.lognorm - ep.half_nu_plus_d * log1p_nonneg(q * ep.inv_nu)
                                      : ep.lognorm - 0.5 * q;
   return ep.out_density ? exp(lp) : lp;
 }

@@ -15,7 +15,10 @@ for d in [int(v) for v in os.environ.get("WIDE_TIME_DS", "192,185,208,224,240,25
     X = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
     out = torch.empty(N, dtype=torch.float64, device="cuda")
     A = rng.standard_normal((d, d))
-    D = cusmc_amd.MultiVariateNormalDistribution(rng.standard_normal(d), A @ A.T / d + np.eye(d), ctx=ctx)
+    if os.environ.get("WIDE_TIME_NU"):  # Student-t instead (the epilogue's log1p)
+        D = cusmc_amd.MultiVariateTStudentDistribution(rng.standard_normal(d), A @ A.T / d + np.eye(d), float(os.environ["WIDE_TIME_NU"]), ctx=ctx)
+    else:
+        D = cusmc_amd.MultiVariateNormalDistribution(rng.standard_normal(d), A @ A.T / d + np.eye(d), ctx=ctx)
     t = timed(lambda: D.pdf_dev(X, out), 20, 5)
     nb = (d + 15) // 16
     flop = 2.0 * nb * (nb + 1) * 2048 / 16
