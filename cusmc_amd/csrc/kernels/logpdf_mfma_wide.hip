@@ -41,10 +41,6 @@
 #include "../../../include/cusmc_hip.h"
 #include "smallops.h"
 
-#ifndef CUSMC_WIDE_DMA_AUX  // cache-policy bits of the loader's LDS-DMA loads (calibration builds: 2 = nt, 16 = sc1, 1 = sc0)
-#define CUSMC_WIDE_DMA_AUX 0
-#endif
-
 namespace cusmc {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -251,7 +247,7 @@ __global__ __launch_bounds__(64 * (wide_waves(NB) + 1)) void logpdf_mfma_wide_ke
 #pragma unroll
           for (int t = 0; t < TILES; ++t) {
             auto *dst = (__attribute__((address_space(3))) void *)(buf + ((kb * 2 + h2) * TILES + t) * 128);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, t * tile_bytes + 128 * kb + 64 * h2, 0, CUSMC_WIDE_DMA_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, t * tile_bytes + 128 * kb + 64 * h2, 0, 0);  // (cache-policy bits nt / sc0 / sc1: no effect, profiles/r03_experiments.txt)
             // Pace the stream: issued as one burst, the group's 64 KB of HBM reads sit in the CU's
             // vector-memory path in front of the compute waves' fragment loads, which then see
             // HBM latency instead of L2 latency (full kernel 672 -> 642 us in the calibration run
